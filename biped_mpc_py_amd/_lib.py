@@ -1,0 +1,86 @@
+"""ctypes binding of libbmpc.so (include/bmpc.h).  No fallback: if the shared library is missing
+or no HIP device is usable, the product path raises -- it never computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbmpc.so")
+
+ABI_VERSION = 1
+
+# every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = (
+    "bmpc_abi_version", "bmpc_last_error", "bmpc_supported_horizon", "bmpc_default_params",
+    "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
+    "bmpc_solve_batch", "bmpc_solve_batch_device", "bmpc_synchronize",
+    "bmpc_debug_assemble", "bmpc_last_kernel_ms",
+)
+
+
+class BmpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbmpc error {code}: {msg}")
+        self.code = code
+
+
+class CParams(C.Structure):
+    """struct bmpc_params (include/bmpc.h)."""
+    _fields_ = [
+        ("h", C.c_int32), ("half", C.c_int32),
+        ("dt", C.c_double), ("kv", C.c_double),
+        ("x_cmd", C.c_double * 12), ("Q", C.c_double * 13), ("R", C.c_double * 12),
+        ("m", C.c_double), ("I", C.c_double * 9),
+        ("lt", C.c_double), ("lh", C.c_double), ("g", C.c_double), ("mu", C.c_double),
+        ("f_max", C.c_double * 3), ("f_min", C.c_double * 3),
+        ("tau_max", C.c_double * 3), ("tau_min", C.c_double * 3),
+        ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("rho_lo", C.c_double),
+        ("rho_hi_f", C.c_double), ("rho_hi_m", C.c_double), ("alpha", C.c_double),
+        ("eps_pri", C.c_double), ("eps_dua", C.c_double),
+        ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
+        ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libbmpc.so once and declare prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  biped_mpc_py_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    lib.bmpc_abi_version.restype = ip
+    lib.bmpc_last_error.restype = C.c_char_p
+    lib.bmpc_supported_horizon.argtypes = [ip]
+    lib.bmpc_default_params.argtypes = [C.POINTER(CParams), ip]
+    lib.bmpc_create.argtypes = [C.POINTER(vp), C.POINTER(CParams), ip, ip]
+    lib.bmpc_destroy.argtypes = [vp]
+    lib.bmpc_set_params.argtypes = [vp, C.POINTER(CParams)]
+    lib.bmpc_get_params.argtypes = [vp, C.POINTER(CParams)]
+    ptrs14 = [vp] * 12
+    lib.bmpc_solve_batch.argtypes = [vp, ip] + ptrs14
+    lib.bmpc_solve_batch_device.argtypes = [vp, ip] + ptrs14 + [vp]
+    lib.bmpc_synchronize.argtypes = [vp]
+    lib.bmpc_debug_assemble.argtypes = [vp, ip] + [vp] * 10
+    lib.bmpc_last_kernel_ms.argtypes = [vp, fp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name != "bmpc_last_error":
+            fn.restype = ip
+    if lib.bmpc_abi_version() != ABI_VERSION:
+        raise ImportError(f"libbmpc ABI {lib.bmpc_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BmpcError(rc, load().bmpc_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,199 @@
+"""Host side of the drop-in: the reference's `solve_mpc` call surface over libbmpc.so.
+
+    states, controls = solve_mpc(x_fb, t, foot, mpc, biped, contact)        # REF:187, 304, 487
+
+returns new fp64 arrays `states (h,13)`, `controls (h,12)` exactly like the reference, so
+`u0 = controls[0, :].reshape(-1, 1)` -> `lowLevelControl(...)` (REF:493-494) keeps working.  The
+three prints of REF:190-192 are not reproduced.  `solve_mpc_batch` is the same for B instances.
+All arithmetic happens in the HIP kernels; this module only marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .params import pack_params, params_key
+
+
+def phase_index(t, mpc_or_dt, h=None):
+    """k = int(t // dt) % h, evaluated in fp64 on the host exactly as REF:56-57 / REF:99-100."""
+    if h is None:
+        dt, h = mpc_or_dt.dt, mpc_or_dt.h
+    else:
+        dt = mpc_or_dt
+    return int(t // dt) % int(h)
+
+
+def get_contact_sequence(t, mpc, half=None):
+    """REF:50-59.  Default: the reference's 20x2 table of 5-on/5-off, rows k..k+9 (ten rows whatever
+    `mpc.h` is -- reference quirk).  With `half` given: half-on/half-off table, rows k..k+h."""
+    if half is None:
+        half_, nrow = 5, 10
+    else:
+        half_, nrow = int(half), int(mpc.h)
+    leg0 = (np.arange(4 * half_) // half_) % 2 == 0
+    table = np.stack([leg0, ~leg0], axis=1).astype(int)
+    k = phase_index(t, mpc)
+    return table[k:k + nrow, :]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchSolver:
+    """Owns one `bmpc_handle` (device memory + stream) for a fixed parameter block."""
+
+    def __init__(self, mpc=None, biped=None, half=None, device=0, max_batch=65536, solver_options=None,
+                 cparams=None):
+        self._lib = _lib.load()
+        self.cparams = cparams if cparams is not None else pack_params(mpc, biped, half, solver_options)
+        self.h = int(self.cparams.h)
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.bmpc_create(C.byref(self._h), C.byref(self.cparams), self.device, self.max_batch))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.bmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host arrays --------------------------------------------------------------------------
+    def _marshal(self, x_fb, foot, contact, phase, x_cmd, mu):
+        h = self.h
+        x_fb = np.ascontiguousarray(np.asarray(x_fb, np.float32).reshape(-1, 12))
+        B = x_fb.shape[0]
+        foot = np.ascontiguousarray(np.asarray(foot, np.float32).reshape(B, 6))
+        contact = np.asarray(contact)
+        if contact.shape[-1] != 2 or contact.size != B * h * 2:
+            raise ValueError(f"contact must have shape (B, {h}, 2)")
+        if not np.isin(contact, (0, 1)).all():
+            raise ValueError("contact entries must be 0 or 1")
+        contact = np.ascontiguousarray(contact.reshape(B, h, 2).astype(np.uint8))
+        phase = np.ascontiguousarray(np.asarray(phase, np.int32).reshape(B))
+        if x_cmd is not None:
+            x_cmd = np.ascontiguousarray(np.asarray(x_cmd, np.float32).reshape(B, 12))
+        if mu is not None:
+            mu = np.ascontiguousarray(np.asarray(mu, np.float32).reshape(B, h, 2))
+        return B, x_fb, foot, contact, phase, x_cmd, mu
+
+    def solve(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_states=True):
+        """Host arrays in, host arrays out (fp32 over PCIe, fp64 returned).  Returns
+        (states (B,h,13) | None, controls (B,h,12), info)."""
+        B, x_fb, foot, contact, phase, x_cmd, mu = self._marshal(x_fb, foot, contact, phase, x_cmd, mu)
+        h = self.h
+        controls = np.empty((B, h, 12), np.float32)
+        states = np.empty((B, h, 13), np.float32) if want_states else None
+        iters = np.empty(B, np.int32)
+        status = np.empty(B, np.int32)
+        nfactor = np.empty(B, np.int32)
+        resid = np.empty((B, 2), np.float32)
+        _lib.check(self._lib.bmpc_solve_batch(
+            self._h, B, _ptr(x_fb), _ptr(foot), _ptr(contact), _ptr(phase), _ptr(x_cmd), _ptr(mu),
+            _ptr(controls), _ptr(states), _ptr(iters), _ptr(resid), _ptr(status), _ptr(nfactor)))
+        info = dict(iters=iters, status=status, nfactor=nfactor, residuals=resid)
+        return (None if states is None else states.astype(np.float64)), controls.astype(np.float64), info
+
+    def assemble(self, x_fb, foot, contact, phase, x_cmd=None, mu=None):
+        """Assembly stage only (parity tests): x_ref (B,h,12), foot_ref (B,h,6), Gt (B,6h,6h), qt (B,6h)."""
+        B, x_fb, foot, contact, phase, x_cmd, mu = self._marshal(x_fb, foot, contact, phase, x_cmd, mu)
+        h = self.h
+        x_ref = np.zeros((B, h, 12)); foot_ref = np.zeros((B, h, 6))
+        Gt = np.zeros((B, 6 * h, 6 * h)); qt = np.zeros((B, 6 * h))
+        _lib.check(self._lib.bmpc_debug_assemble(
+            self._h, B, _ptr(x_fb), _ptr(foot), _ptr(contact), _ptr(phase), _ptr(x_cmd), _ptr(mu),
+            _ptr(x_ref), _ptr(foot_ref), _ptr(Gt), _ptr(qt)))
+        return x_ref, foot_ref, Gt, qt
+
+    # ---- device-resident (torch tensors are only a way to own HBM and a stream) ----------------
+    def solve_device(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, controls=None, states=None,
+                     iters=None, residuals=None, status=None, nfactor=None, stream=None):
+        """Inputs/outputs are CUDA(HIP) torch tensors on this solver's device (fp32 / uint8 / int32,
+        contiguous).  Asynchronous on `stream` (default: torch's current stream).  Returns the
+        output tensors; nothing crosses PCIe."""
+        import torch
+        B = x_fb.shape[0]
+        h = self.h
+        dev = x_fb.device
+
+        def chk(t, dtype, shape):
+            if t is None:
+                return 0
+            if t.device != dev or t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != shape:
+                raise ValueError(f"expected contiguous {dtype} tensor of shape {shape} on {dev}")
+            return t.data_ptr()
+
+        if dev.type != "cuda" or dev.index != self.device:
+            raise ValueError(f"tensors must live on cuda:{self.device}")
+        if controls is None:
+            controls = torch.empty((B, h, 12), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(self._lib.bmpc_solve_batch_device(
+            self._h, B, chk(x_fb, torch.float32, (B, 12)), chk(foot, torch.float32, (B, 6)),
+            chk(contact, torch.uint8, (B, h, 2)), chk(phase, torch.int32, (B,)),
+            chk(x_cmd, torch.float32, (B, 12)) or None, chk(mu, torch.float32, (B, h, 2)) or None,
+            chk(controls, torch.float32, (B, h, 12)), chk(states, torch.float32, (B, h, 13)) or None,
+            chk(iters, torch.int32, (B,)) or None, chk(residuals, torch.float32, (B, 2)) or None,
+            chk(status, torch.int32, (B,)) or None, chk(nfactor, torch.int32, (B,)) or None, st))
+        return controls, states
+
+    def last_kernel_ms(self):
+        ms = C.c_float(-1.0)
+        _lib.check(self._lib.bmpc_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def synchronize(self):
+        _lib.check(self._lib.bmpc_synchronize(self._h))
+
+
+_SOLVERS = {}
+
+
+def _cached_solver(mpc, biped, half, device, solver_options):
+    cp = pack_params(mpc, biped, half, solver_options)
+    key = (params_key(cp), int(device))
+    s = _SOLVERS.get(key)
+    if s is None:
+        s = BatchSolver(cparams=cp, device=device)
+        _SOLVERS[key] = s
+    return s
+
+
+def solve_mpc_batch(x_fb, t, foot, contact, mpc=None, biped=None, x_cmd=None, mu=None, phase=None, half=None,
+                    device=0, solver_options=None, return_info=False):
+    """B instances of REF:187 `solve_mpc`.  x_fb (B,12), t (B,) seconds [or phase (B,) directly],
+    foot (B,6), contact (B,h,2); optional per-instance x_cmd (B,12) and mu (B,h,2).
+    Returns states (B,h,13), controls (B,h,12) [, info]."""
+    from .params import MPC
+    mpc = mpc if mpc is not None else MPC()
+    solver = _cached_solver(mpc, biped, half, device, solver_options)
+    if phase is None:
+        tt = np.asarray(t, float).reshape(-1)
+        phase = np.array([phase_index(v, mpc) for v in tt], np.int32)
+    states, controls, info = solver.solve(x_fb, foot, contact, phase, x_cmd=x_cmd, mu=mu)
+    if return_info:
+        return states, controls, info
+    return states, controls
+
+
+def solve_mpc(x_fb, t, foot, mpc, biped, contact, half=None, device=0, solver_options=None):
+    """Drop-in for REF:187-304: same arguments, same return shapes and dtypes (fp64 `states (h,13)`,
+    `controls (h,12)`), inputs not mutated, silent."""
+    h = int(mpc.h)
+    contact = np.asarray(contact)
+    if contact.ndim != 2 or contact.shape[1] != 2 or contact.shape[0] < h:
+        raise ValueError(f"contact must have at least {h} rows of 2 (REF:239-249 indexes contact[k] for k < h)")
+    x_fb = np.asarray(x_fb, float).reshape(12)
+    foot = np.asarray(foot, float).reshape(6)
+    states, controls = solve_mpc_batch(x_fb[None], [t], foot[None], contact[None, :h, :], mpc=mpc, biped=biped,
+                                       half=half, device=device, solver_options=solver_options)
+    return states[0], controls[0]

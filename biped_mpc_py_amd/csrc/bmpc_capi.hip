@@ -1,0 +1,335 @@
+// bmpc_capi.hip -- C ABI (include/bmpc.h) over the HIP kernels.  Built into libbmpc.so.
+// There is deliberately no CPU path here: without a HIP device every entry point that would
+// compute returns BMPC_ERR_NO_DEVICE.
+#include "bmpc_kernels.hip"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "bmpc.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(BMPC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+bool inv3(const double* a, double* o) {
+  const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  if (!(std::fabs(det) > 0)) return false;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+  o[3] = c01 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+  return true;
+}
+
+int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
+  if (!bmpc_supported_horizon(p.h)) return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", p.h);
+  if (p.half < 1) return fail(BMPC_ERR_INVALID, "half must be >= 1");
+  if (!(p.dt > 0) || !(p.m > 0)) return fail(BMPC_ERR_INVALID, "dt and m must be positive");
+  if (!(p.rho > 0) || !(p.rho_lo > 0) || !(p.rho_hi_f > 0) || !(p.rho_hi_m > 0) || !(p.rho_eq_scale > 0))
+    return fail(BMPC_ERR_INVALID, "penalties must be positive");
+  if (p.max_iter < 1 || p.check_every < 1) return fail(BMPC_ERR_INVALID, "max_iter, check_every must be >= 1");
+  std::memset(d, 0, sizeof(*d));
+  d->h = p.h; d->half = p.half; d->max_iter = p.max_iter; d->check_every = p.check_every;
+  d->adapt_start = p.adapt_start; d->adapt_every = p.adapt_every; d->max_refactor = p.max_refactor;
+  d->dt = p.dt; d->kv = p.kv; d->m = p.m; d->g = p.g; d->mu = p.mu;
+  d->lt = p.lt - 0.01;                       // REF:254
+  d->lh = p.lh - 0.02;                       // REF:255
+  d->alpha = p.alpha;
+  for (int i = 0; i < 12; ++i) {
+    d->x_cmd[i] = p.x_cmd[i];
+    d->Q[i] = p.Q[i];
+    d->R2[i] = 2.0 * p.R[i];
+    if (!(p.R[i] > 0) || !(p.Q[i] >= 0)) return fail(BMPC_ERR_INVALID, "need R > 0, Q >= 0");
+  }
+  if (!inv3(p.I, d->Iinv)) return fail(BMPC_ERR_INVALID, "inertia matrix is singular");
+  for (int i = 0; i < 3; ++i) {
+    d->f_max[i] = p.f_max[i]; d->f_min[i] = p.f_min[i];
+    d->tau_max[i] = p.tau_max[i]; d->tau_min[i] = p.tau_min[i];
+    if (p.f_max[i] < p.f_min[i] || p.tau_max[i] < p.tau_min[i]) return fail(BMPC_ERR_INVALID, "upper bound below lower bound");
+  }
+  d->rho = (float)p.rho; d->rho_eq = (float)(p.rho * p.rho_eq_scale); d->rho_lo = (float)p.rho_lo;
+  d->rho_hi_f = (float)p.rho_hi_f; d->rho_hi_m = (float)p.rho_hi_m;
+  d->eps_pri = (float)p.eps_pri; d->eps_dua = (float)p.eps_dua;
+  return BMPC_OK;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct bmpc_handle_s {
+  int device = 0;
+  int max_batch = 0;
+  bmpc_params params;
+  bmpc::DevParams dev;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  // staging for the host-pointer entry points
+  DevBuf<float> x_fb, foot, x_cmd, mu, controls, states, resid;
+  DevBuf<uint8_t> contact;
+  DevBuf<int32_t> phase, iters, status, nfactor;
+  DevBuf<double> dbg;
+};
+
+namespace {
+
+template <int H>
+int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+             const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+             int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
+             hipStream_t st) {
+  constexpr int NT = bmpc::Dims<H>::NT;
+  hipLaunchKernelGGL((bmpc::solve_kernel<H, double>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
+                     phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg);
+  HIP_TRY(hipGetLastError());
+  return BMPC_OK;
+}
+
+int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+           const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+           int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
+           hipStream_t st) {
+  switch (hd->dev.h) {
+    case 10: return launch_h<10>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+    case 16: return launch_h<16>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+    case 20: return launch_h<20>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+    default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
+  }
+}
+
+int check_common(bmpc_handle h, int B, const void* x_fb, const void* foot, const void* contact, const void* phase,
+                 const void* controls) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B > 0 && (!x_fb || !foot || !contact || !phase || !controls))
+    return fail(BMPC_ERR_INVALID, "x_fb, foot, contact, phase and controls must be non-null");
+  return BMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmpc_abi_version(void) { return BMPC_ABI_VERSION; }
+
+const char* bmpc_last_error(void) { return g_err; }
+
+int bmpc_supported_horizon(int h) { return (h == 10 || h == 16 || h == 20) ? 1 : 0; }
+
+int bmpc_default_params(bmpc_params* p, int h) {
+  if (!p) return fail(BMPC_ERR_INVALID, "null params");
+  std::memset(p, 0, sizeof(*p));
+  p->h = h;
+  p->half = (h == 10) ? 5 : (h > 1 ? h / 2 : 1);                      // REF:101 hard-codes 5 at h = 10
+  p->dt = 0.04;                                                       // REF:25
+  p->kv = 0.01;                                                       // REF:29
+  const double xc[12] = {0, 0, 0, 0, 0, 0.55, 0, 0, 0, 0, 0, 0};       // REF:26
+  const double Q[13] = {500, 100, 100, 300, 300, 700, 1, 1, 1, 1, 1, 1, 1};   // REF:27
+  for (int i = 0; i < 12; ++i) { p->x_cmd[i] = xc[i]; p->R[i] = 1e-4; }       // REF:28
+  for (int i = 0; i < 13; ++i) p->Q[i] = Q[i];
+  p->m = 12;                                                          // REF:36
+  p->I[0] = 0.932; p->I[4] = 0.9420; p->I[8] = 0.0711;                // REF:37-39
+  p->lt = 0.09; p->lh = 0.05; p->g = 9.81; p->mu = 0.5;               // REF:40-44
+  for (int i = 0; i < 3; ++i) { p->f_max[i] = 500; p->f_min[i] = 0; } // REF:45-46
+  p->tau_max[0] = 0; p->tau_max[1] = 67; p->tau_max[2] = 33.5;        // REF:47
+  for (int i = 0; i < 3; ++i) p->tau_min[i] = -p->tau_max[i];         // REF:48
+  p->rho = 0.01; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 0.1; p->rho_hi_m = 1.0;
+  p->alpha = 1.6; p->eps_pri = 1e-6; p->eps_dua = 1e-6;
+  p->max_iter = 400; p->check_every = 5; p->adapt_start = 20; p->adapt_every = 10; p->max_refactor = 12;
+  return BMPC_OK;
+}
+
+int bmpc_create(bmpc_handle* out, const bmpc_params* params, int device, int max_batch) {
+  if (!out || !params) return fail(BMPC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (max_batch < 1) return fail(BMPC_ERR_INVALID, "max_batch must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(BMPC_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(BMPC_ERR_INVALID, "device %d outside [0, %d)", device, ndev);
+  bmpc::DevParams dev;
+  int rc = make_dev_params(*params, &dev);
+  if (rc != BMPC_OK) return rc;
+  bmpc_handle h = new (std::nothrow) bmpc_handle_s();
+  if (!h) return fail(BMPC_ERR_ALLOC, "out of host memory");
+  h->device = device; h->max_batch = max_batch; h->params = *params; h->dev = dev;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e != hipSuccess) {
+    bmpc_destroy(h);
+    return fail(BMPC_ERR_HIP, "bmpc_create: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return BMPC_OK;
+}
+
+int bmpc_destroy(bmpc_handle h) {
+  if (!h) return BMPC_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->x_fb.release(); h->foot.release(); h->x_cmd.release(); h->mu.release(); h->controls.release();
+  h->states.release(); h->resid.release(); h->contact.release(); h->phase.release(); h->iters.release();
+  h->status.release(); h->nfactor.release(); h->dbg.release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return BMPC_OK;
+}
+
+int bmpc_set_params(bmpc_handle h, const bmpc_params* params) {
+  if (!h || !params) return fail(BMPC_ERR_INVALID, "null argument");
+  if (params->h != h->params.h) return fail(BMPC_ERR_INVALID, "horizon is fixed at creation (h=%d)", h->params.h);
+  bmpc::DevParams dev;
+  int rc = make_dev_params(*params, &dev);
+  if (rc != BMPC_OK) return rc;
+  h->params = *params; h->dev = dev;
+  return BMPC_OK;
+}
+
+int bmpc_get_params(bmpc_handle h, bmpc_params* out) {
+  if (!h || !out) return fail(BMPC_ERR_INVALID, "null argument");
+  *out = h->params;
+  return BMPC_OK;
+}
+
+int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                            const int32_t* phase, const float* x_cmd, const float* mu, float* controls,
+                            float* states, int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
+                            void* stream) {
+  int rc = check_common(h, B, x_fb, foot, contact, phase, controls);
+  if (rc != BMPC_OK) return rc;
+  if (B == 0) return BMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  bmpc::DebugOut dbg = {nullptr, nullptr, nullptr, nullptr, 0};
+  HIP_TRY(hipEventRecord(h->ev0, st));
+  rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st);
+  if (rc != BMPC_OK) return rc;
+  HIP_TRY(hipEventRecord(h->ev1, st));
+  h->timed = true;
+  return BMPC_OK;
+}
+
+int bmpc_solve_batch(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                     const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+                     int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor) {
+  int rc = check_common(h, B, x_fb, foot, contact, phase, controls);
+  if (rc != BMPC_OK) return rc;
+  if (B == 0) return BMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B, H = (size_t)h->dev.h;
+  HIP_TRY(h->x_fb.ensure(n * 12)); HIP_TRY(h->foot.ensure(n * 6)); HIP_TRY(h->contact.ensure(n * H * 2));
+  HIP_TRY(h->phase.ensure(n)); HIP_TRY(h->controls.ensure(n * H * 12)); HIP_TRY(h->states.ensure(n * H * 13));
+  HIP_TRY(h->iters.ensure(n)); HIP_TRY(h->status.ensure(n)); HIP_TRY(h->nfactor.ensure(n)); HIP_TRY(h->resid.ensure(n * 2));
+  if (x_cmd) HIP_TRY(h->x_cmd.ensure(n * 12));
+  if (mu) HIP_TRY(h->mu.ensure(n * H * 2));
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->x_fb.p, x_fb, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->foot.p, foot, n * 6 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->contact.p, contact, n * H * 2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->phase.p, phase, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if (x_cmd) HIP_TRY(hipMemcpyAsync(h->x_cmd.p, x_cmd, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  if (mu) HIP_TRY(hipMemcpyAsync(h->mu.p, mu, n * H * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+  rc = bmpc_solve_batch_device(h, B, h->x_fb.p, h->foot.p, h->contact.p, h->phase.p, x_cmd ? h->x_cmd.p : nullptr,
+                               mu ? h->mu.p : nullptr, h->controls.p, states ? h->states.p : nullptr, h->iters.p,
+                               h->resid.p, h->status.p, h->nfactor.p, st);
+  if (rc != BMPC_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(controls, h->controls.p, n * H * 12 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (states) HIP_TRY(hipMemcpyAsync(states, h->states.p, n * H * 13 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, h->iters.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (status) HIP_TRY(hipMemcpyAsync(status, h->status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (nfactor) HIP_TRY(hipMemcpyAsync(nfactor, h->nfactor.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (residuals) HIP_TRY(hipMemcpyAsync(residuals, h->resid.p, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
+int bmpc_synchronize(bmpc_handle h) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return BMPC_OK;
+}
+
+int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                        const int32_t* phase, const float* x_cmd, const float* mu, double* x_ref, double* foot_ref,
+                        double* Gt, double* qt) {
+  float dummy = 0;
+  int rc = check_common(h, B, x_fb, foot, contact, phase, &dummy);
+  if (rc != BMPC_OK) return rc;
+  if (B == 0) return BMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B, H = (size_t)h->dev.h, NW = 6 * H;
+  HIP_TRY(h->x_fb.ensure(n * 12)); HIP_TRY(h->foot.ensure(n * 6)); HIP_TRY(h->contact.ensure(n * H * 2));
+  HIP_TRY(h->phase.ensure(n)); HIP_TRY(h->controls.ensure(n * H * 12));
+  if (x_cmd) HIP_TRY(h->x_cmd.ensure(n * 12));
+  if (mu) HIP_TRY(h->mu.ensure(n * H * 2));
+  const size_t o_xr = 0, o_fr = o_xr + n * H * 12, o_gt = o_fr + n * H * 6, o_qt = o_gt + n * NW * NW, tot = o_qt + n * NW;
+  HIP_TRY(h->dbg.ensure(tot));
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemsetAsync(h->dbg.p, 0, tot * sizeof(double), st));
+  HIP_TRY(hipMemcpyAsync(h->x_fb.p, x_fb, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->foot.p, foot, n * 6 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->contact.p, contact, n * H * 2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->phase.p, phase, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if (x_cmd) HIP_TRY(hipMemcpyAsync(h->x_cmd.p, x_cmd, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  if (mu) HIP_TRY(hipMemcpyAsync(h->mu.p, mu, n * H * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+  bmpc::DebugOut dbg = {h->dbg.p + o_xr, h->dbg.p + o_fr, h->dbg.p + o_gt, h->dbg.p + o_qt, 1};
+  rc = launch(h, B, h->x_fb.p, h->foot.p, h->contact.p, h->phase.p, x_cmd ? h->x_cmd.p : nullptr,
+              mu ? h->mu.p : nullptr, h->controls.p, nullptr, nullptr, nullptr, nullptr, nullptr, dbg, st);
+  if (rc != BMPC_OK) return rc;
+  if (x_ref) HIP_TRY(hipMemcpyAsync(x_ref, h->dbg.p + o_xr, n * H * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (foot_ref) HIP_TRY(hipMemcpyAsync(foot_ref, h->dbg.p + o_fr, n * H * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (Gt) HIP_TRY(hipMemcpyAsync(Gt, h->dbg.p + o_gt, n * NW * NW * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (qt) HIP_TRY(hipMemcpyAsync(qt, h->dbg.p + o_qt, n * NW * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
+int bmpc_last_kernel_ms(bmpc_handle h, float* ms) {
+  if (!h || !ms) return fail(BMPC_ERR_INVALID, "null argument");
+  *ms = -1.f;
+  if (!h->timed) return BMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return BMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,941 @@
+// bmpc_kernels.hip -- HIP kernels (gfx950 / CDNA4) for the batched HECTOR force-and-moment MPC.
+//
+// One workgroup solves one MPC instance end to end; a launch covers a batch.  Nothing but the
+// ~1.2 KB/instance of compulsory I/O touches HBM: the whole working set (wrench-space Hessian row,
+// K^-1 row, per-step 6x6 blocks, iterates) lives in VGPRs and LDS.
+//
+// What is computed (citations: REF = /root/reference/bipedalLocomotionMPC.py, read-only spec):
+//   references       x_ref, foot_ref                               REF:61-109
+//   SRBM step data   Rot, I_w^-1, R_inv, r_f = foot - com          REF:148-185
+//   condensing       X = s + Gam_t b, b_j = W_j u_j (net wrench)   REF:203-216 eliminated analytically
+//   cost             Gt = 2 Gam_t' Q Gam_t, qt = 2 Gam_t' Q (s - x_ref),  + u'Ru     REF:278-286
+//   constraints      box (REF:235-251), friction pyramid (REF:220-232), line foot (REF:254-271)
+//   solve            the unique minimiser REF:297 asks cvxopt for, by ADMM with active-set adaptive
+//                    penalties; unpack controls / states (REF:300-304)
+//
+// Thread map: lane l < 6H  <->  (step j = l / 6, component c = l % 6).  A lane owns
+//   * wrench row c of step j (tau_xyz, F_xyz): one row of Gt and of V = (Gt + F)^-1 in VGPRs,
+//   * control variable c of both feet at step j (v = [f(3), m(3)] per foot),
+//   * the box row of those two variables and general row c (4 friction + 2 line-foot) of both feet.
+// Arithmetic: data and the preconditioner K^-1 (V sweep, V mat-vec, 6x6 blocks) are f32; the
+// iterates and the KKT residual the preconditioner is applied to are RT (f64 by default), which is
+// what pins the fixed point to the fp64 optimum.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmpc {
+
+struct DevParams {
+  int h, half, max_iter, check_every, adapt_start, adapt_every, max_refactor, pad0;
+  double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
+  double x_cmd[12], Q[12], R2[12], Iinv[9];    // R2 = 2 R;  Iinv = inverse body inertia
+  double f_max[3], f_min[3], tau_max[3], tau_min[3];
+  float rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m, eps_pri, eps_dua, pad1;
+};
+
+struct DebugOut {            // all nullable, fp64, device pointers
+  double* x_ref;             // [B][H][12]
+  double* foot_ref;          // [B][H][6]
+  double* Gt;                // [B][6H][6H]
+  double* qt;                // [B][6H]
+  int assemble_only;
+};
+
+template <int H>
+struct Dims {
+  static constexpr int NW = 6 * H;                       // wrench rows = threads that work
+  static constexpr int NT = ((NW + 63) / 64) * 64;       // threads per workgroup (whole waves)
+  static constexpr int NPAIR = H * (H - 1) / 2;          // (i > j) step pairs
+};
+
+// LDS image of one instance.
+template <int H, typename RT>
+struct alignas(16) Smem {
+  static constexpr int NW = Dims<H>::NW;
+  // iteration vectors
+  RT xt[H][2][6];            // x tilde
+  RT wg[H][2][6];            // y + rho (A x - z) on the general rows
+  RT bw[NW];                 // net wrench of x
+  RT gb[NW];                 // wrench-space gradient Gt b + qt
+  alignas(16) float r32[H][2][6];   // KKT residual, control space
+  alignas(16) float beta[NW];
+  alignas(16) float gam[NW];
+  alignas(16) float piv[2][NW];     // sweep pivot column, double buffered
+  // block-diagonal part of K^-1
+  alignas(16) float L[H][2][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
+  alignas(16) float Na[H][2][6][12];    // N Ka^-1 N'            [foot][var][foot*6 + var]
+  // step data (setup)
+  RT Iw[H][9];               // world inverse inertia
+  RT Rv[H][9];               // R_inv (REF:160-164)
+  RT Pre[H][9];              // prefix sums of R_inv
+  RT rr[H][2][3];            // r_f = foot_ref - com_ref
+  RT err[H][12];             // free response - reference
+  RT Me[Dims<H>::NPAIR > 0 ? Dims<H>::NPAIR : 1][9];   // dt^2 (P_i - P_j) Iw_j, i > j
+  // factor scratch
+  float rvg[H][2][6];
+  float M0[H][6][6], M1[H][6][6], M2[H][6][6];   // D0 / D1 / Ka, then their inverses
+  float F[H][6][6];
+  float ex[H][4][6];         // pivot-column exchange for the cooperative 6x6 sweeps
+  float red[4][Dims<H>::NT / 64];
+  int flag[2];
+};
+
+__device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
+
+// max over the workgroup of up to 4 values at once.
+template <int NT>
+__device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] = fmaxf(v[q], __shfl_xor(v[q], o, 64));
+  }
+  if constexpr (NT > 64) {
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][w] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float m = red[q][0];
+#pragma unroll
+      for (int w2 = 1; w2 < NT / 64; ++w2) m = fmaxf(m, red[q][w2]);
+      v[q] = m;
+    }
+    __syncthreads();
+  }
+}
+
+// Cooperative symmetric sweep of NM 6x6 SPD matrices per step: lane (j, c) holds row c of each.
+// On exit the rows hold the INVERSES.  All threads of the workgroup must call (barriers inside).
+template <int H, typename RT, int NM>
+__device__ __forceinline__ void sweep6(float (&m)[NM][6], Smem<H, RT>& sm, bool valid, int j, int c) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < NM; ++q) sm.ex[j][q][c] = m[q][k];
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < NM; ++q) {
+        float col[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) col[b] = sm.ex[j][q][b];
+        const float pinv = 1.0f / col[k];
+        const bool isp = (c == k);
+        const float t = isp ? -pinv : m[q][k] * pinv;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          if (b == k) continue;
+          m[q][b] = isp ? col[b] * pinv : fmaf(-t, col[b], m[q][b]);
+        }
+        m[q][k] = t;            // pivot lane: -1/p ; others: a_ik / p
+      }
+    }
+    __syncthreads();
+  }
+  // swept matrix = -A^-1
+#pragma unroll
+  for (int q = 0; q < NM; ++q)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m[q][b] = -m[q][b];
+}
+
+__device__ __forceinline__ void sincos_rt(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void sincos_rt(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ double min_rt(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float min_rt(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double max_rt(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float max_rt(float a, float b) { return fmaxf(a, b); }
+
+// a[idx] for a runtime idx without demoting the array to scratch
+template <int N, typename T>
+__device__ __forceinline__ T pick(const T (&a)[N], int idx) {
+  T v = a[0];
+#pragma unroll
+  for (int q = 1; q < N; ++q) v = (q == idx) ? a[q] : v;
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void cross3(const T* a, const T* b, T* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// General (non-box) rows of one foot block over v = [f(3), m(3)]:
+// rows 0..3 friction (+x, +y, -x, -y; REF:220-229), rows 4, 5 line foot (REF:259-262).
+__device__ __forceinline__ void general_rows(float mu, const float* ey, const float* ez, float lh,
+                                             float lt, float (&G)[6][6]) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) G[r][b] = 0.f;
+  G[0][0] = 1.f;  G[0][2] = -mu;
+  G[1][1] = 1.f;  G[1][2] = -mu;
+  G[2][0] = -1.f; G[2][2] = -mu;
+  G[3][1] = -1.f; G[3][2] = -mu;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    G[4][b] = -lh * ez[b];  G[4][3 + b] = ey[b];
+    G[5][b] = -lt * ez[b];  G[5][3 + b] = -ey[b];
+  }
+}
+
+template <int H, typename RT>
+__global__ void __launch_bounds__(Dims<H>::NT)
+solve_kernel(const DevParams P, const int B,
+             const float* __restrict__ x_fb, const float* __restrict__ foot,
+             const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase,
+             const float* __restrict__ x_cmd, const float* __restrict__ mu_in,
+             float* __restrict__ controls, float* __restrict__ states,
+             int32_t* __restrict__ iters_out, float* __restrict__ resid_out,
+             int32_t* __restrict__ status_out, int32_t* __restrict__ nfactor_out,
+             const DebugOut dbg) {
+  constexpr int NW = Dims<H>::NW;
+  constexpr int NT = Dims<H>::NT;
+  __shared__ Smem<H, RT> sm;
+
+  const int inst = blockIdx.x;
+  if (inst >= B) return;
+  const int l = threadIdx.x;
+  const bool valid = l < NW;
+  const int j = valid ? l / 6 : 0;
+  const int c = valid ? l % 6 : 0;
+  const RT dt = (RT)P.dt;
+
+  // ------------------------------------------------------------------ A. references, step data
+  RT xfb[12], xc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    xfb[i] = (RT)x_fb[(size_t)inst * 12 + i];
+    xc[i] = x_cmd ? (RT)x_cmd[(size_t)inst * 12 + i] : (RT)P.x_cmd[i];
+  }
+  const int kph = phase[inst];
+  RT xr[12];                                   // x_ref[:, j]  (REF:61-70)
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    if (j == 0) xr[i] = xfb[i];
+    else if (i < 6) xr[i] = (xc[i + 6] != (RT)0) ? xfb[i] + xc[i + 6] * ((RT)j * dt) : xc[i];
+    else xr[i] = xc[i];
+  }
+  RT fr[6];                                    // foot_ref[:, j]  (REF:72-109)
+  {
+    const int c0 = contact[(size_t)inst * H * 2 + 0], c1 = contact[(size_t)inst * H * 2 + 1];
+    const bool single = (c0 + c1) == 1;        // REF:102
+    const int kk = kph % P.half;               // REF:101
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fr[i] = (RT)foot[(size_t)inst * 6 + i];
+    if (single && j >= P.half - kk) {
+      const bool second = j >= 2 * P.half - kk;
+      const RT hor = second ? (RT)0.5 * (RT)H * dt : (RT)0.5 * (RT)H / (RT)2 * dt;   // REF:74, 78
+      const RT fx = xfb[3] + xfb[9] * hor + (RT)P.kv * (xfb[3] - xc[3]);
+      const RT fy = (second ? xfb[10] : xfb[4]) + xfb[10] * hor + (RT)P.kv * (xfb[4] - xc[4]);  // REF:87 quirk
+      fr[0] = fx; fr[1] = fy; fr[2] = 0; fr[3] = fx; fr[4] = fy; fr[5] = 0;
+    }
+  }
+  if (dbg.x_ref && valid) {
+    dbg.x_ref[((size_t)inst * H + j) * 12 + c] = (double)pick(xr, c);
+    dbg.x_ref[((size_t)inst * H + j) * 12 + 6 + c] = (double)pick(xr, 6 + c);
+  }
+  if (dbg.foot_ref && valid) dbg.foot_ref[((size_t)inst * H + j) * 6 + c] = (double)pick(fr, c);
+
+  RT Pj[9];                                    // prefix sum of R_inv up to this lane's step
+  {
+    RT sy, cy, sp, cp, sr, cr;                 // REF:151-153: yaw = x[0], pitch = x[1], roll = x[2]
+    sincos_rt(xr[0], &sy, &cy);
+    sincos_rt(xr[1], &sp, &cp);
+    sincos_rt(xr[2], &sr, &cr);
+    // Rot = Rx(roll) Ry(pitch) Rz(yaw)   (scipy 'zyx' extrinsic, REF:154-156)
+    const RT Rot[9] = {cp * cy, -cp * sy, sp,
+                       cr * sy + sr * sp * cy, cr * cy - sr * sp * sy, -sr * cp,
+                       sr * sy - cr * sp * cy, sr * cy + cr * sp * sy, cr * cp};
+    RT T[9], Iw[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        T[3 * a + b] = (RT)P.Iinv[3 * a] * Rot[b] + (RT)P.Iinv[3 * a + 1] * Rot[3 + b] + (RT)P.Iinv[3 * a + 2] * Rot[6 + b];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        Iw[3 * a + b] = Rot[a] * T[b] + Rot[3 + a] * T[3 + b] + Rot[6 + a] * T[6 + b];   // Rot' Iinv Rot = (Rot' I Rot)^-1
+    const RT tp = sp / cp;
+    const RT Rv[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};             // REF:160-164 inverted
+    if (valid && c == 0) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { sm.Iw[j][q] = Iw[q]; sm.Rv[j][q] = Rv[q]; }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sm.rr[j][f][a] = fr[3 * f + a] - xr[3 + a];           // REF:174-175
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 9; ++q) Pj[q] = 0;
+#pragma unroll 1
+  for (int s = 0; s <= j; ++s)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Pj[q] += sm.Rv[s][q];
+  if (valid) {
+    if (c == 0) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) sm.Pre[j][q] = Pj[q];
+    }
+    // free response s_j - x_ref[:, j]   (X_j is the state after step j)
+    const RT j1 = (RT)(j + 1);
+    RT e12[12];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      e12[a] = xfb[a] + dt * (Pj[3 * a] * xfb[6] + Pj[3 * a + 1] * xfb[7] + Pj[3 * a + 2] * xfb[8]);
+      e12[3 + a] = xfb[3 + a] + dt * j1 * xfb[9 + a];
+      e12[6 + a] = xfb[6 + a];
+      e12[9 + a] = xfb[9 + a];
+    }
+    e12[5] -= (RT)P.g * dt * dt * (RT)j * j1 / 2;
+    e12[11] -= (RT)P.g * dt * j1;
+    sm.err[j][c] = pick(e12, c) - pick(xr, c);
+    sm.err[j][c + 6] = pick(e12, c + 6) - pick(xr, c + 6);
+  }
+  __syncthreads();
+  // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2
+  {
+    int idx = 0;
+#pragma unroll 1
+    for (int i = 1; i < H; ++i)
+#pragma unroll 1
+      for (int j2 = 0; j2 < i; ++j2, ++idx) {
+        if (idx % NT != l) continue;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            RT s = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) s += (sm.Pre[i][3 * a + q] - sm.Pre[j2][3 * a + q]) * sm.Iw[j2][3 * q + b];
+            sm.Me[idx][3 * a + b] = dt * dt * s;
+          }
+      }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ B. wrench-space Hessian row
+  float Grow[3 * H];          // torque lanes: Gt[(j,a)][(j2,b<3)] at 3 j2 + b ; force lanes: Gt[(j,a)][(j2,a)] at j2
+  RT qt = 0;
+#pragma unroll
+  for (int q = 0; q < 3 * H; ++q) Grow[q] = 0.f;
+  if (valid) {
+    if (c < 3) {
+      const int a = c;
+      RT nw[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) nw[q] = dt * sm.Iw[j][3 * q + a] * (RT)P.Q[6 + q];   // Q_w weighted column
+#pragma unroll
+      for (int j2 = 0; j2 < H; ++j2) {
+        const int mx = j > j2 ? j : j2;
+        RT acc[3] = {0, 0, 0};
+#pragma unroll 1
+        for (int i = mx + 1; i < H; ++i) {
+          const RT* m1 = sm.Me[pair_index(i, j)];
+          const RT* m2 = sm.Me[pair_index(i, j2)];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const RT u = m1[3 * q + a] * (RT)P.Q[q];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[b] += u * m2[3 * q + b];
+          }
+        }
+        const RT cnt = (RT)(H - mx);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          RT s = 0;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) s += nw[q] * dt * sm.Iw[j2][3 * q + b];
+          const RT gval = 2 * (acc[b] + cnt * s);
+          Grow[3 * j2 + b] = (float)gval;
+          if (dbg.Gt) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + b] = (double)gval;
+        }
+      }
+      RT s = 0;
+#pragma unroll 1
+      for (int i = j; i < H; ++i) {
+        if (i > j) {
+          const RT* m1 = sm.Me[pair_index(i, j)];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) s += m1[3 * q + a] * (RT)P.Q[q] * sm.err[i][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s += nw[q] * sm.err[i][6 + q];
+      }
+      qt = 2 * s;
+    } else {
+      const int a = c - 3;
+      const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
+#pragma unroll
+      for (int j2 = 0; j2 < H; ++j2) {
+        const int mx = j > j2 ? j : j2;
+        RT s2 = 0;
+#pragma unroll 1
+        for (int i = mx; i < H; ++i) s2 += (RT)((i - j) * (i - j2));
+        const RT gval = 2 * ((RT)P.Q[3 + a] * kp * kp * s2 + (RT)P.Q[9 + a] * kvv * kvv * (RT)(H - mx));
+        Grow[j2] = (float)gval;
+        if (dbg.Gt) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + 3 + a] = (double)gval;
+      }
+      RT s = 0;
+#pragma unroll 1
+      for (int i = j; i < H; ++i)
+        s += kp * (RT)(i - j) * (RT)P.Q[3 + a] * sm.err[i][3 + a] + kvv * (RT)P.Q[9 + a] * sm.err[i][9 + a];
+      qt = 2 * s;
+    }
+    if (dbg.qt) dbg.qt[(size_t)inst * NW + l] = (double)qt;
+  }
+  if (dbg.assemble_only) return;
+
+  // ------------------------------------------------------------------ C. constraint data
+  float ey[3], ez[3];                         // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
+  {
+    RT sr, cr, sp, cp, sy, cy;
+    sincos_rt(xfb[0], &sr, &cr);
+    sincos_rt(xfb[1], &sp, &cp);
+    sincos_rt(xfb[2], &sy, &cy);
+    ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
+    ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
+  }
+  const float lh = (float)P.lh, lt = (float)P.lt;
+  float muf[2], lb[2], ub[2], R2v[2];
+  bool eqb[2];
+  float grow[2][6], gcol[2][6];               // this lane's general row / its variable's column
+  float rf[2][3];                             // lever arms of this step
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const float cont = (float)contact[((size_t)inst * H + j) * 2 + f];
+    muf[f] = mu_in ? mu_in[((size_t)inst * H + j) * 2 + f] : (float)P.mu;
+    const int a = c < 3 ? c : c - 3;
+    ub[f] = cont * (float)(c < 3 ? P.f_max[a] : P.tau_max[a]);      // REF:240-249
+    lb[f] = cont * (float)(c < 3 ? P.f_min[a] : P.tau_min[a]);
+    eqb[f] = lb[f] == ub[f];
+    R2v[f] = (float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
+    float G[6][6];
+    general_rows(muf[f], ey, ez, lh, lt, G);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float gr = 0.f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) gr = (r == c) ? G[r][b] : gr;   // runtime c: select row c
+      grow[f][b] = gr;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float gc = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) gc = (b == c) ? G[r][b] : gc;
+      gcol[f][r] = gc;
+    }
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2) rf[f][a2] = (float)sm.rr[j][f][a2];
+  }
+
+  // ------------------------------------------------------------------ D. factor: L, Na, V for penalties rv
+  float rvb[2], rvg[2];                       // penalties of this lane's box rows / general rows
+#pragma unroll
+  for (int f = 0; f < 2; ++f) { rvb[f] = eqb[f] ? P.rho_eq : P.rho; rvg[f] = P.rho; }
+  float Vrow[NW];                             // row l of -(Gt + F)^-1 after the sweep
+  float Lcol[2][6];                           // L[j][f][i][c] for beta
+
+  auto factor = [&]() {
+    // D_f = 2R + A' diag(rv) A, row c of both feet
+    if (valid) {
+      sm.rvg[j][0][c] = rvg[0];
+      sm.rvg[j][1][c] = rvg[1];
+    }
+    __syncthreads();
+    float m3[3][6];                            // rows of D0, D1, Ka
+    float Tm[6][6];                            // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
+    {
+      const float dr[3] = {rf[0][0] - rf[1][0], rf[0][1] - rf[1][1], rf[0][2] - rf[1][2]};
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Tm[p][q] = (p == q) ? 1.f : 0.f;
+      Tm[3][1] = -dr[2]; Tm[3][2] = dr[1];
+      Tm[4][0] = dr[2];  Tm[4][2] = -dr[0];
+      Tm[5][0] = -dr[1]; Tm[5][1] = dr[0];
+    }
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float G[6][6];
+        general_rows(muf[f], ey, ez, lh, lt, G);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          float s = 0.f;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) s = fmaf(sm.rvg[j][f][r] * gcol[f][r], G[r][b], s);
+          m3[f][b] = s + ((b == c) ? (R2v[f] + rvb[f]) : 0.f);
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) (f == 0 ? sm.M0 : sm.M1)[j][c][b] = m3[f][b];
+      }
+    }
+    __syncthreads();
+    if (valid) {                               // Ka = D0 + T' D1 T, row c
+      float yq[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          float tpc = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc) tpc = (cc == c) ? Tm[p][cc] : tpc;
+          s = fmaf(tpc, sm.M1[j][p][q], s);
+        }
+        yq[q] = s;
+      }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        float s = m3[0][b];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s = fmaf(yq[q], Tm[q][b], s);
+        m3[2][b] = s;
+      }
+    }
+    __syncthreads();                           // M1 reads done before it is overwritten
+    sweep6<H, RT, 3>(m3, sm, valid, j, c);     // -> D0^-1, D1^-1, Ka^-1
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) { sm.M0[j][c][b] = m3[0][b]; sm.M1[j][c][b] = m3[1][b]; sm.M2[j][c][b] = m3[2][b]; }
+    }
+    __syncthreads();
+    // E = sum_f W_f D_f^-1 W_f',  W_f = [[r_f]x, I; I, 0]
+    float e1[1][6];
+    float Wm[2][6][6];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Wm[f][p][q] = 0.f;
+      Wm[f][0][1] = -rf[f][2]; Wm[f][0][2] = rf[f][1];
+      Wm[f][1][0] = rf[f][2];  Wm[f][1][2] = -rf[f][0];
+      Wm[f][2][0] = -rf[f][1]; Wm[f][2][1] = rf[f][0];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { Wm[f][a][3 + a] = 1.f; Wm[f][3 + a][a] = 1.f; }
+    }
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) e1[0][b] = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float yq[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          float s = 0.f;
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            float wcp = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) wcp = (cc == c) ? Wm[f][cc][p] : wcp;
+            s = fmaf(wcp, (f == 0 ? sm.M0 : sm.M1)[j][p][q], s);
+          }
+          yq[q] = s;
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) e1[0][b] = fmaf(yq[q], Wm[f][b][q], e1[0][b]);
+      }
+    }
+    sweep6<H, RT, 1>(e1, sm, valid, j, c);     // -> F = E^-1
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) sm.F[j][c][b] = e1[0][b];
+    }
+    __syncthreads();
+    if (valid) {
+      // L_f = D_f^-1 W_f' F, row c (variable c of foot f)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float xq[6];                           // (D_f^-1 W_f')[c][p] = sum_q Dinv[c][q] W[p][q]
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) s = fmaf(m3[f][q], Wm[f][p][q], s);
+          xq[p] = s;
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          float s = 0.f;
+#pragma unroll
+          for (int p = 0; p < 6; ++p) s = fmaf(xq[p], sm.F[j][p][b], s);
+          sm.L[j][f][c][b] = s;
+        }
+      }
+      // Na = N Ka^-1 N', N_0 = I, N_1 = -T
+      float kt[6];                             // (Ka^-1 T')[c][b]
+      float tk[6];                             // (T Ka^-1)[c][b]
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          s = fmaf(m3[2][q], Tm[b][q], s);
+          float tcq = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc) tcq = (cc == c) ? Tm[cc][q] : tcq;
+          s2 = fmaf(tcq, sm.M2[j][q][b], s2);
+        }
+        kt[b] = s;
+        tk[b] = s2;
+      }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        sm.Na[j][0][c][b] = m3[2][b];
+        sm.Na[j][0][c][6 + b] = -kt[b];
+        sm.Na[j][1][c][b] = -tk[b];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s = fmaf(tk[q], Tm[b][q], s);
+        sm.Na[j][1][c][6 + b] = s;
+      }
+    }
+    __syncthreads();
+    // K' row = Gt row + F row on the own step; then symmetric sweep with a rotating register file:
+    // at step k register r holds column (r + k) mod NW, so the pivot column is always register 0.
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const int j2 = q / 6, b = q % 6;
+        float v;
+        if (c < 3) v = (b < 3) ? Grow[3 * j2 + b] : 0.f;
+        else v = (b == c) ? Grow[j2] : 0.f;
+        Vrow[q] = v;
+      }
+#pragma unroll
+      for (int j2 = 0; j2 < H; ++j2) {
+        if (j2 == j) {
+#pragma unroll
+          for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] += sm.F[j][c][b];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Lcol[f][i] = sm.L[j][f][i][c];
+    }
+#pragma unroll 1
+    for (int k = 0; k < NW; ++k) {
+      float* buf = sm.piv[k & 1];
+      if (valid) {
+        int pos = l - k;
+        pos += (pos < 0) ? NW : 0;
+        buf[pos] = Vrow[0];
+      }
+      __syncthreads();
+      if (valid) {
+        const float pinv = 1.0f / buf[0];
+        const bool isp = (l == k);
+        const float t = isp ? -pinv : Vrow[0] * pinv;
+#pragma unroll
+        for (int r = 1; r < NW; ++r) {
+          const float base = isp ? 0.f : Vrow[r];
+          Vrow[r - 1] = fmaf(-t, buf[r], base);
+        }
+        Vrow[NW - 1] = t;
+      }
+    }
+  };
+
+  int nfac = 0;
+  bool need_factor = true;
+
+  // ------------------------------------------------------------------ E. ADMM iterations
+  RT xo[2] = {0, 0};                          // own variables
+  RT zb[2] = {0, 0}, zg[2] = {0, 0}, yb[2] = {0, 0}, yg[2] = {0, 0};
+  RT xblk[2][6];                              // both foot blocks of this step (redundant per lane)
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) xblk[f][b] = 0;
+  const RT alpha = (RT)P.alpha;
+  int it = 0, status = 1;
+  float res_p = 0.f, res_s = 0.f;
+
+#pragma unroll 1
+  for (it = 0; it < P.max_iter;) {
+    if (need_factor) {                         // workgroup-uniform
+      factor();
+      ++nfac;
+      need_factor = false;
+    }
+    // --- E1: row residuals w = y + rho (A x - z), net wrench of x
+    RT wb[2];
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        RT axg = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) axg += (RT)grow[f][b] * xblk[f][b];
+        wb[f] = yb[f] + (RT)rvb[f] * (xo[f] - zb[f]);
+        sm.wg[j][f][c] = yg[f] + (RT)rvg[f] * (axg - zg[f]);
+      }
+      RT val;
+      if (c < 3) {
+        RT t0[3], t1[3];
+        const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
+        const RT r1[3] = {sm.rr[j][1][0], sm.rr[j][1][1], sm.rr[j][1][2]};
+        cross3(r0, &xblk[0][0], t0);
+        cross3(r1, &xblk[1][0], t1);
+        RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
+                    t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
+        val = c == 0 ? v3[0] : (c == 1 ? v3[1] : v3[2]);
+      } else {
+        RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
+        val = c == 3 ? v3[0] : (c == 4 ? v3[1] : v3[2]);
+      }
+      sm.bw[l] = val;
+    }
+    __syncthreads();
+    // --- E2: wrench-space gradient gb = Gt b + qt
+    if (valid) {
+      RT g = qt;
+      if (c < 3) {
+#pragma unroll
+        for (int j2 = 0; j2 < H; ++j2)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) g += (RT)Grow[3 * j2 + b] * sm.bw[6 * j2 + b];
+      } else {
+#pragma unroll
+        for (int j2 = 0; j2 < H; ++j2) g += (RT)Grow[j2] * sm.bw[6 * j2 + c];
+      }
+      sm.gb[l] = g;
+    }
+    __syncthreads();
+    // --- E3: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
+    if (valid) {
+      RT gt3[3] = {sm.gb[6 * j], sm.gb[6 * j + 1], sm.gb[6 * j + 2]};
+      RT gf3[3] = {sm.gb[6 * j + 3], sm.gb[6 * j + 4], sm.gb[6 * j + 5]};
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        RT r = (RT)R2v[f] * xo[f] + wb[f];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) r += (RT)gcol[f][q] * sm.wg[j][f][q];
+        RT wt;
+        if (c < 3) {
+          const RT rfd[3] = {sm.rr[j][f][0], sm.rr[j][f][1], sm.rr[j][f][2]};
+          RT cr3[3];
+          cross3(gt3, rfd, cr3);               // [r]x' g_tau = g_tau x r
+          wt = (c == 0 ? cr3[0] + gf3[0] : (c == 1 ? cr3[1] + gf3[1] : cr3[2] + gf3[2]));
+        } else {
+          wt = (c == 3 ? gt3[0] : (c == 4 ? gt3[1] : gt3[2]));
+        }
+        sm.r32[j][f][c] = (float)(r + wt);
+      }
+    }
+    __syncthreads();
+    // --- E4: beta = L' r
+    float rj[2][6];
+    if (valid) {
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          rj[f][i] = sm.r32[j][f][i];
+          s = fmaf(Lcol[f][i], rj[f][i], s);
+        }
+      sm.beta[l] = s;
+    }
+    __syncthreads();
+    // --- E5: gamma = V beta   (Vrow holds -V)
+    if (valid) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; q += 4) {
+        const float4 bq = *reinterpret_cast<const float4*>(&sm.beta[q]);
+        s0 = fmaf(Vrow[q], bq.x, s0);
+        s1 = fmaf(Vrow[q + 1], bq.y, s1);
+        s2 = fmaf(Vrow[q + 2], bq.z, s2);
+        s3 = fmaf(Vrow[q + 3], bq.w, s3);
+      }
+      sm.gam[l] = -((s0 + s1) + (s2 + s3));
+    }
+    __syncthreads();
+    // --- E6: x~ = x - (Na r + L gamma)
+    RT xto[2];
+    if (valid) {
+      float gm[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gm[i] = sm.gam[6 * j + i];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) s = fmaf(sm.Na[j][f][c][6 * g + i], rj[g][i], s);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s = fmaf(sm.L[j][f][c][i], gm[i], s);
+        xto[f] = xo[f] - (RT)s;
+        sm.xt[j][f][c] = xto[f];
+      }
+    }
+    __syncthreads();
+    // --- E7: z~ = A x~, relaxation, projection, dual update
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        RT xtb[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) xtb[b] = sm.xt[j][f][b];
+        RT ztg = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) ztg += (RT)grow[f][b] * xtb[b];
+        const RT ztb = xto[f];
+        // box row
+        {
+          const RT zr = alpha * ztb + (1 - alpha) * zb[f];
+          const RT cand = zr + yb[f] / (RT)rvb[f];
+          const RT zn = min_rt(max_rt(cand, (RT)lb[f]), (RT)ub[f]);
+          yb[f] += (RT)rvb[f] * (zr - zn);
+          zb[f] = zn;
+          rp = fmaxf(rp, fabsf((float)(ztb - zn)));
+          nz = fmaxf(nz, fabsf((float)ztb));
+        }
+        // general row: l = -inf, u = 0
+        {
+          const RT zr = alpha * ztg + (1 - alpha) * zg[f];
+          const RT cand = zr + yg[f] / (RT)rvg[f];
+          const RT zn = min_rt(cand, (RT)0);
+          yg[f] += (RT)rvg[f] * (zr - zn);
+          zg[f] = zn;
+          rp = fmaxf(rp, fabsf((float)(ztg - zn)));
+          nz = fmaxf(nz, fabsf((float)ztg));
+        }
+        rs = fmaxf(rs, fabsf((float)(xto[f] - xo[f])));
+        nx = fmaxf(nx, fabsf((float)xto[f]));
+#pragma unroll
+        for (int b = 0; b < 6; ++b) xblk[f][b] = alpha * xtb[b] + (1 - alpha) * xblk[f][b];
+        xo[f] = alpha * xto[f] + (1 - alpha) * xo[f];
+      }
+    }
+    ++it;
+    // --- stopping test (workgroup-uniform)
+    if (it % P.check_every == 0 || it == P.max_iter) {
+      float v4[4] = {rp, rs, nz, nx};
+      block_max4<NT>(v4, sm.red);
+      res_p = v4[0];
+      res_s = v4[1];
+      const bool bad = !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
+      if (bad) { status = 2; break; }
+      if (v4[0] <= P.eps_pri * fmaxf(1.f, v4[2]) && v4[1] <= P.eps_dua * fmaxf(1.f, v4[3])) { status = 0; break; }
+    }
+    // --- penalty re-classification by the current active set
+    if (P.adapt_every > 0 && it >= P.adapt_start && (it - P.adapt_start) % P.adapt_every == 0 &&
+        nfac <= P.max_refactor) {
+      int changed = 0;
+      float nb[2], ng[2];
+      if (valid) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const bool actb = (zb[f] <= (RT)lb[f] || zb[f] >= (RT)ub[f]) && yb[f] != (RT)0;
+          const bool actg = (zg[f] >= (RT)0) && yg[f] != (RT)0;
+          nb[f] = eqb[f] ? P.rho_eq : (actb ? (c < 3 ? P.rho_hi_f : P.rho_hi_m) : P.rho_lo);
+          ng[f] = actg ? (c < 4 ? P.rho_hi_f : P.rho_hi_m) : P.rho_lo;
+          changed |= (nb[f] != rvb[f]) | (ng[f] != rvg[f]);
+        }
+      }
+      changed = __syncthreads_or(changed);
+      if (changed) {
+        if (valid) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) { rvb[f] = nb[f]; rvg[f] = ng[f]; }
+        }
+        need_factor = true;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ F. outputs (REF:300-304)
+  if (valid) {
+    float* uo = controls + ((size_t)inst * H + j) * 12;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
+      uo[pos] = (float)xo[f];
+    }
+  }
+  if (states) {
+    // wrench of the final x, then X_i = s_i + Gam_t b
+    __syncthreads();
+    if (valid) {
+      RT val;
+      if (c < 3) {
+        RT t0[3], t1[3];
+        const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
+        const RT r1[3] = {sm.rr[j][1][0], sm.rr[j][1][1], sm.rr[j][1][2]};
+        cross3(r0, &xblk[0][0], t0);
+        cross3(r1, &xblk[1][0], t1);
+        RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
+                    t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
+        val = c == 0 ? v3[0] : (c == 1 ? v3[1] : v3[2]);
+      } else {
+        RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
+        val = c == 3 ? v3[0] : (c == 4 ? v3[1] : v3[2]);
+      }
+      sm.bw[l] = val;
+    }
+    __syncthreads();
+    if (valid) {
+      float* so = states + ((size_t)inst * H + j) * 13;
+      const int i = j;
+      if (c < 3) {
+        const int a = c;
+        // euler: s + sum_{j2 < i} Me[i][j2] tau_j2 ; omega: w_fb + dt sum_{j2 <= i} Iw_j2 tau_j2
+        RT e = sm.err[i][a], w = sm.err[i][6 + a];
+#pragma unroll 1
+        for (int j2 = 0; j2 <= i; ++j2) {
+          const RT t3[3] = {sm.bw[6 * j2], sm.bw[6 * j2 + 1], sm.bw[6 * j2 + 2]};
+          if (j2 < i) {
+            const RT* m1 = sm.Me[pair_index(i, j2)];
+            e += m1[3 * a] * t3[0] + m1[3 * a + 1] * t3[1] + m1[3 * a + 2] * t3[2];
+          }
+          w += dt * (sm.Iw[j2][3 * a] * t3[0] + sm.Iw[j2][3 * a + 1] * t3[1] + sm.Iw[j2][3 * a + 2] * t3[2]);
+        }
+        so[a] = (float)(e + pick(xr, a));
+        so[6 + a] = (float)(w + pick(xr, 6 + a));
+      } else {
+        const int a = c - 3;
+        RT p = sm.err[i][3 + a], v = sm.err[i][9 + a];
+        const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
+#pragma unroll 1
+        for (int j2 = 0; j2 <= i; ++j2) {
+          const RT fa = sm.bw[6 * j2 + 3 + a];
+          p += kp * (RT)(i - j2) * fa;
+          v += kvv * fa;
+        }
+        so[3 + a] = (float)(p + pick(xr, 3 + a));
+        so[9 + a] = (float)(v + pick(xr, 9 + a));
+      }
+      if (c == 0) so[12] = 1.0f;
+    }
+  }
+  if (l == 0) {
+    if (iters_out) iters_out[inst] = it;
+    if (status_out) status_out[inst] = status;
+    if (nfactor_out) nfactor_out[inst] = nfac;
+    if (resid_out) { resid_out[2 * inst] = res_p; resid_out[2 * inst + 1] = res_s; }
+  }
+}
+
+}  // namespace bmpc

@@ -1,0 +1,152 @@
+/*
+ * bmpc.h -- C ABI of libbmpc.so: batched HECTOR force-and-moment MPC on MI355X (gfx950).
+ *
+ * Drop-in boundary for the hot path of junhengl/biped_mpc_py (REF = bipedalLocomotionMPC.py):
+ * one call solves B independent instances of what REF:187-304 `solve_mpc` solves once.
+ * The reference has no FFI of its own (it is one Python file); these entry points are what a
+ * ctypes binding replacing the body of `solve_mpc` would call.
+ *
+ * Conventions: plain C, no torch / HIP types in signatures.  All arrays are row-major and
+ * instance-major.  Every function returns 0 on success or a negative bmpc_status code;
+ * bmpc_last_error() gives a thread-local message.  A handle owns its device memory and stream;
+ * one handle is not thread-safe, distinct handles are.  Per-instance failures (iteration cap,
+ * NaN) are reported in status[], never by failing the batch.
+ */
+#ifndef BMPC_H
+#define BMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMPC_ABI_VERSION 1
+
+enum bmpc_status {
+  BMPC_OK = 0,
+  BMPC_ERR_INVALID = -1,     /* bad argument (null pointer, B > max_batch, unsupported h ...) */
+  BMPC_ERR_NO_DEVICE = -2,   /* no usable HIP device: the library never falls back to the CPU */
+  BMPC_ERR_HIP = -3,         /* a HIP runtime call failed */
+  BMPC_ERR_ALLOC = -4
+};
+
+/* per-instance status[] values written by the solver */
+enum bmpc_instance_status {
+  BMPC_SOLVED = 0,           /* stopping criteria met */
+  BMPC_MAX_ITER = 1,         /* iteration cap reached (result is the last iterate) */
+  BMPC_NUMERICAL = 2         /* NaN/Inf encountered */
+};
+
+/*
+ * Parameter block.  Field names follow the reference's attribute bags:
+ *   MPC   (REF:22-32): h, dt, x_cmd, Q, R, kv
+ *   Biped (REF:34-48): m, I, lt, lh, g, mu, f_max, f_min, tau_max, tau_min
+ * plus the solver's own knobs.  `half` is the gait half period used by the reference-foot
+ * generator (REF:101-105 hard-codes 5).  bmpc_default_params() fills the reference defaults.
+ */
+typedef struct bmpc_params {
+  int32_t h;                 /* horizon length (REF:24); supported: see bmpc_supported_horizon */
+  int32_t half;              /* gait half period in steps (REF:101: 5) */
+  double dt;                 /* REF:25 */
+  double kv;                 /* REF:29 */
+  double x_cmd[12];          /* REF:26; used when the per-instance x_cmd argument is NULL */
+  double Q[13];              /* REF:27 (13th weight acts on the constant state: inert) */
+  double R[12];              /* REF:28 */
+  double m;                  /* REF:36 */
+  double I[9];               /* REF:37-39 body inertia, row-major */
+  double lt, lh;             /* REF:40-41 (the 0.01 / 0.02 margins of REF:254-255 are applied inside) */
+  double g;                  /* REF:42 */
+  double mu;                 /* REF:44; used when the per-instance mu argument is NULL */
+  double f_max[3], f_min[3];     /* REF:45-46 */
+  double tau_max[3], tau_min[3]; /* REF:47-48 */
+  /* solver (ADMM with active-set adaptive penalties) */
+  double rho;                /* initial penalty on every row */
+  double rho_eq_scale;       /* multiplier for rows with l == u (pinned variables) */
+  double rho_lo;             /* penalty of rows classified inactive */
+  double rho_hi_f;           /* penalty of active force-like rows (force box, friction) */
+  double rho_hi_m;           /* penalty of active moment-like rows (moment box, line-foot) */
+  double alpha;              /* over-relaxation */
+  double eps_pri, eps_dua;   /* relative stopping tolerances */
+  int32_t max_iter;
+  int32_t check_every;       /* stopping test period */
+  int32_t adapt_start;       /* first penalty re-classification */
+  int32_t adapt_every;       /* re-classification period (0 = never) */
+  int32_t max_refactor;      /* cap on re-factorisations per instance */
+  int32_t reserved;
+} bmpc_params;
+
+typedef struct bmpc_handle_s* bmpc_handle;
+
+/* Library / ABI identification. */
+int bmpc_abi_version(void);
+const char* bmpc_last_error(void);
+/* 1 if a kernel is built for this horizon, else 0. */
+int bmpc_supported_horizon(int h);
+/* Reference defaults (REF:22-48) and solver defaults for horizon h. */
+int bmpc_default_params(bmpc_params* p, int h);
+
+/* Create a solver bound to HIP device `device` for at most max_batch instances per call.
+ * Replaces: constructing MPC() / Biped() (REF:475-476) -- the parameters are uploaded once. */
+int bmpc_create(bmpc_handle* out, const bmpc_params* params, int device, int max_batch);
+int bmpc_destroy(bmpc_handle h);
+/* Replace the parameter block (same horizon as at creation). */
+int bmpc_set_params(bmpc_handle h, const bmpc_params* params);
+int bmpc_get_params(bmpc_handle h, bmpc_params* out);
+
+/*
+ * Solve B instances; HOST pointers.  Replaces REF:187-304 solve_mpc for a batch.
+ *   x_fb     [B][12]   state feedback (REF:13 ordering: euler, pos, omega_w, v_w)
+ *   foot     [B][6]    world foot positions [foot1 xyz, foot2 xyz] (REF:479)
+ *   contact  [B][h][2] 0/1 contact schedule (REF:482-484)
+ *   phase    [B]       k = int(t // dt) % h (REF:99-100), computed by the caller in fp64
+ *   x_cmd    [B][12]   or NULL -> params.x_cmd
+ *   mu       [B][h][2] or NULL -> params.mu
+ * outputs
+ *   controls [B][h][12] row k = [f1 f2 m1 m2] (REF:302)
+ *   states   [B][h][13] or NULL; row k = predicted state at step k+1 (REF:301)
+ *   iters    [B] or NULL, residuals [B][2] or NULL (primal, step), status [B] or NULL
+ *   nfactor  [B] or NULL: factorisations used
+ * Synchronous: returns after the results are in the output arrays.
+ */
+int bmpc_solve_batch(bmpc_handle h, int B,
+                     const float* x_fb, const float* foot, const uint8_t* contact,
+                     const int32_t* phase, const float* x_cmd, const float* mu,
+                     float* controls, float* states,
+                     int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor);
+
+/*
+ * Same, DEVICE pointers (memory of the handle's device), asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the handle's own stream).  Nothing is copied.
+ * This is the entry the bench times and the one a device-resident control loop uses.
+ */
+int bmpc_solve_batch_device(bmpc_handle h, int B,
+                            const float* x_fb, const float* foot, const uint8_t* contact,
+                            const int32_t* phase, const float* x_cmd, const float* mu,
+                            float* controls, float* states,
+                            int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
+                            void* stream);
+
+/* Block until everything queued on the handle's own stream is done. */
+int bmpc_synchronize(bmpc_handle h);
+
+/*
+ * Introspection for parity tests of the assembly stage (DEVICE->HOST copy inside).
+ * Runs the assembly only and returns, per instance, in fp64:
+ *   x_ref [B][h][12] (REF:61-70), foot_ref [B][h][6] (REF:72-109),
+ *   Gt [B][6h][6h] wrench-space Hessian, qt [B][6h] wrench-space gradient,
+ * any of which may be NULL.
+ */
+int bmpc_debug_assemble(bmpc_handle h, int B,
+                        const float* x_fb, const float* foot, const uint8_t* contact,
+                        const int32_t* phase, const float* x_cmd, const float* mu,
+                        double* x_ref, double* foot_ref, double* Gt, double* qt);
+
+/* Time of the last bmpc_solve_batch* kernel launch on the handle's stream, measured with HIP
+ * events around the launch (milliseconds); <0 if none.  Forces a stream synchronise. */
+int bmpc_last_kernel_ms(bmpc_handle h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMPC_H */

@@ -290,10 +290,10 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
         yn = y + rvr * (zr - zn)
         if (it + 1) % P.check_every == 0:
             rp = np.abs(zt - zn).reshape(B, -1).max(1)
-            rd = np.abs(np.einsum("bhfri,bhfr->bhfi", Ar, rvr * (z - zt) + yn - y)).reshape(B, -1).max(1)
+            rs = np.abs(xt - x).reshape(B, -1).max(1)                     # preconditioned residual K^-1 r
             sc_p = np.maximum(np.abs(zt).reshape(B, -1).max(1), 1)
-            sc_d = np.maximum(np.abs(np.einsum("bhfri,bhfr->bhfi", Ar, yn)).reshape(B, -1).max(1), 1)
-            done = (rp <= P.eps_pri * sc_p) & (rd <= P.eps_dua * sc_d)
+            sc_d = np.maximum(np.abs(xt).reshape(B, -1).max(1), 1)
+            done = (rp <= P.eps_pri * sc_p) & (rs <= P.eps_dua * sc_d)
             newly = active & done
             it_done[newly] = it + 1
             if iters is None:

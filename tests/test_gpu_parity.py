@@ -1,0 +1,116 @@
+"""GPU parity: the HIP path through the C ABI against the oracle's certified optima (golden
+fixtures) and against the oracle itself on fresh seeded inputs.  Tolerance: 1e-4 relative force
+error (north_star), measured as SURVEY 8(d) defines it."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(h, half, **opts):
+    import biped_mpc_py_amd as bm
+    mpc = bm.MPC()
+    mpc.h = h
+    return bm.BatchSolver(mpc=mpc, half=half, solver_options=opts or None), mpc
+
+
+@pytest.mark.parametrize("name", list(util.BATCH_FIXTURES))
+def test_golden_batches(name):
+    h, half = util.BATCH_FIXTURES[name]
+    d = util.load(name)
+    solver, mpc = _solver(h, half)
+    mu = d["mu_steps"] if "mu_steps" in d.files and d["mu_steps"].size else None
+    states, controls, info = solver.solve(d["x_fb"], d["foot"], d["contact"], util.phases(d["t"], mpc.dt, h),
+                                          x_cmd=d["x_cmd"], mu=mu)
+    e = util.rel_err(controls, d["controls"])
+    es = util.rel_err(states, d["states"])
+    print(name, "ctrl err max %.2e  state err max %.2e  iters mean %.1f max %d  nfactor mean %.1f" %
+          (e.max(), es.max(), info["iters"].mean(), info["iters"].max(), info["nfactor"].mean()))
+    assert (info["status"] == 0).all(), info["status"]
+    assert e.max() <= util.REL_TOL
+    assert es.max() <= util.REL_TOL
+
+
+@pytest.mark.parametrize("name", ["known_standing", "known_walking_t0"])
+def test_known_answers_dropin(name):
+    """The reference's own call surface (REF:487, 493-494) on its two default cases."""
+    import biped_mpc_py_amd as bm
+    d = util.load(name)
+    mpc, biped = bm.MPC(), bm.Biped()
+    states, controls = bm.solve_mpc(d["x_fb"], float(d["t"]), d["foot"], mpc, biped, d["contact"])
+    assert states.shape == (10, 13) and controls.shape == (10, 12)
+    assert states.dtype == np.float64 and controls.dtype == np.float64
+    assert util.rel_err(controls[None], d["controls"][None]).max() <= util.REL_TOL
+    assert np.abs(states - d["states"]).max() <= 1e-4 * max(1.0, np.abs(d["states"]).max())
+    u0 = controls[0, :].reshape(-1, 1)
+    assert u0.shape == (12, 1)
+
+
+def test_assembly_matches_model():
+    """x_ref / foot_ref against the reference-pinned fixtures; Gt, qt against the fp64 model."""
+    from oracle import ws_model as ws
+    d = util.load("cfg4_walking_h10")
+    solver, mpc = _solver(10, 5)
+    ph = util.phases(d["t"], mpc.dt, 10)
+    x_ref, foot_ref, Gt, qt = solver.assemble(d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"])
+    assert np.abs(x_ref.transpose(0, 2, 1) - d["x_ref"][:, :12]).max() < 1e-6
+    assert np.abs(foot_ref.transpose(0, 2, 1) - d["foot_ref"]).max() < 1e-6
+    P = ws.Params()
+    _, _, info = ws.solve_batch(P, d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"], dtype=np.float64,
+                                iters=1, return_debug=True)
+    assert np.abs(Gt - info["Gt"]).max() <= 2e-6 * np.abs(info["Gt"]).max()
+    assert np.abs(qt - info["qt"]).max() <= 2e-6 * np.abs(info["qt"]).max()
+
+
+@pytest.mark.parametrize("h,gait,seed,kw", [
+    (10, "standing", 1, {}),
+    (10, "mixed", 3, dict(vx_cmd=True)),
+    (16, "walking", 2, dict(vx_cmd=True)),
+    (20, "walking", 4, dict(vx_cmd=True, per_step_mu=True)),
+])
+def test_fresh_seeded_vs_oracle(h, gait, seed, kw):
+    """Same seeded inputs through the HIP path and through the oracle (sizes the oracle does in seconds)."""
+    from oracle import bmpc_oracle as orc
+    B = 24
+    s = util.synth_batch(B, h, 1000 + seed, gait=gait, **kw)
+    solver, mpc = _solver(h, s["half"])
+    states, controls, info = solver.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])
+    ref_c = np.zeros_like(controls)
+    for i in range(B):
+        m, b = orc.MPC(), orc.Biped()
+        m.h = h
+        m.x_cmd = s["x_cmd"][i]
+        t = s["phase"][i] * m.dt + 0.5 * m.dt
+        x32 = s["x_fb"][i].astype(np.float32).astype(float)
+        f32 = s["foot"][i].astype(np.float32).astype(float)
+        mu_i = None if s["mu"] is None else s["mu"][i].astype(np.float32).astype(float)
+        _, ref_c[i] = orc.solve_mpc(x32, t, f32, m, b, s["contact"][i], half=s["half"], mu_steps=mu_i)
+    e = util.rel_err(controls, ref_c)
+    print(h, gait, "err max %.2e  iters mean %.1f" % (e.max(), info["iters"].mean()))
+    assert e.max() <= util.REL_TOL
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (B = 4096): size-independent properties -- feasibility of every
+    constraint, consistency of states with the dynamics roll-out, determinism, batch invariance."""
+    B, h = 4096, 10
+    s = util.synth_batch(B, h, 1, gait="standing")
+    solver, mpc = _solver(h, 5)
+    states, controls, info = solver.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    assert (info["status"] == 0).all()
+    f = controls.reshape(B, h, 4, 3)
+    tol = 2e-3
+    for j in range(2):
+        fx, fy, fz = f[:, :, j, 0], f[:, :, j, 1], f[:, :, j, 2]
+        assert (fz >= -tol).all() and (fz <= 500 + tol).all()
+        assert (np.abs(fx) <= 0.5 * fz + tol).all() and (np.abs(fy) <= 0.5 * fz + tol).all()
+        assert (np.abs(f[:, :, 2 + j, 0]) <= tol).all()                       # tau_max[0] = 0 (REF:47)
+    # same inputs -> bitwise same outputs; a sub-batch gives the same rows
+    _, c2, _ = solver.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    assert np.array_equal(controls, c2)
+    _, c3, _ = solver.solve(s["x_fb"][100:164], s["foot"][100:164], s["contact"][100:164], s["phase"][100:164],
+                            x_cmd=s["x_cmd"][100:164])
+    assert np.array_equal(controls[100:164], c3)
+    print("iters mean %.1f max %d, nfactor mean %.2f" % (info["iters"].mean(), info["iters"].max(), info["nfactor"].mean()))
