@@ -36,7 +36,7 @@ class CParams(C.Structure):
         ("f_max", C.c_double * 3), ("f_min", C.c_double * 3),
         ("tau_max", C.c_double * 3), ("tau_min", C.c_double * 3),
         ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("rho_lo", C.c_double),
-        ("rho_hi_f", C.c_double), ("rho_hi_m", C.c_double), ("alpha", C.c_double),
+        ("rho_hi_f", C.c_double), ("rho_hi_m", C.c_double), ("kappa", C.c_double), ("alpha", C.c_double),
         ("eps_pri", C.c_double), ("eps_dua", C.c_double),
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
         ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("reserved", C.c_int32),

@@ -46,6 +46,7 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   if (!(p.dt > 0) || !(p.m > 0)) return fail(BMPC_ERR_INVALID, "dt and m must be positive");
   if (!(p.rho > 0) || !(p.rho_lo > 0) || !(p.rho_hi_f > 0) || !(p.rho_hi_m > 0) || !(p.rho_eq_scale > 0))
     return fail(BMPC_ERR_INVALID, "penalties must be positive");
+  if (!(p.kappa > 1)) return fail(BMPC_ERR_INVALID, "kappa must be > 1");
   if (p.max_iter < 1 || p.check_every < 1) return fail(BMPC_ERR_INVALID, "max_iter, check_every must be >= 1");
   std::memset(d, 0, sizeof(*d));
   d->h = p.h; d->half = p.half; d->max_iter = p.max_iter; d->check_every = p.check_every;
@@ -68,7 +69,7 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   }
   d->rho = (float)p.rho; d->rho_eq = (float)(p.rho * p.rho_eq_scale); d->rho_lo = (float)p.rho_lo;
   d->rho_hi_f = (float)p.rho_hi_f; d->rho_hi_m = (float)p.rho_hi_m;
-  d->eps_pri = (float)p.eps_pri; d->eps_dua = (float)p.eps_dua;
+  d->eps_pri = (float)p.eps_pri; d->eps_dua = (float)p.eps_dua; d->kappa = (float)p.kappa;
   return BMPC_OK;
 }
 
@@ -166,9 +167,9 @@ int bmpc_default_params(bmpc_params* p, int h) {
   for (int i = 0; i < 3; ++i) { p->f_max[i] = 500; p->f_min[i] = 0; } // REF:45-46
   p->tau_max[0] = 0; p->tau_max[1] = 67; p->tau_max[2] = 33.5;        // REF:47
   for (int i = 0; i < 3; ++i) p->tau_min[i] = -p->tau_max[i];         // REF:48
-  p->rho = 0.01; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 0.1; p->rho_hi_m = 1.0;
+  p->rho = 0.1; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 10.0;
   p->alpha = 1.6; p->eps_pri = 1e-6; p->eps_dua = 1e-6;
-  p->max_iter = 400; p->check_every = 5; p->adapt_start = 20; p->adapt_every = 10; p->max_refactor = 12;
+  p->max_iter = 400; p->check_every = 5; p->adapt_start = 20; p->adapt_every = 10; p->max_refactor = 40;
   return BMPC_OK;
 }
 

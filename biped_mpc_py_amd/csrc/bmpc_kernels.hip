@@ -31,7 +31,7 @@ struct DevParams {
   double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
   double x_cmd[12], Q[12], R2[12], Iinv[9];    // R2 = 2 R;  Iinv = inverse body inertia
   double f_max[3], f_min[3], tau_max[3], tau_min[3];
-  float rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m, eps_pri, eps_dua, pad1;
+  float rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m, eps_pri, eps_dua, kappa;
 };
 
 struct DebugOut {            // all nullable, fp64, device pointers
@@ -71,12 +71,13 @@ struct alignas(16) Smem {
   RT Pre[H][9];              // prefix sums of R_inv
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
   RT err[H][12];             // free response - reference
-  RT Me[Dims<H>::NPAIR > 0 ? Dims<H>::NPAIR : 1][9];   // dt^2 (P_i - P_j) Iw_j, i > j
+  float Me[Dims<H>::NPAIR > 0 ? Dims<H>::NPAIR : 1][9];   // dt^2 (P_i - P_j) Iw_j, i > j (data: f32)
   // factor scratch
   float rvg[H][2][6];
-  float M0[H][6][6], M1[H][6][6], M2[H][6][6];   // D0 / D1 / Ka, then their inverses
-  float F[H][6][6];
-  float ex[H][4][6];         // pivot-column exchange for the cooperative 6x6 sweeps
+  double M0[H][6][6];        // D0 -> D0^-1 -> F
+  double M1[H][6][6];        // D1 -> D1^-1
+  double M2[H][6][6];        // Ka^-1
+  double ex[H][3][6];        // pivot-column exchange for the cooperative 6x6 sweeps
   float red[4][Dims<H>::NT / 64];
   int flag[2];
 };
@@ -112,7 +113,7 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
 // Cooperative symmetric sweep of NM 6x6 SPD matrices per step: lane (j, c) holds row c of each.
 // On exit the rows hold the INVERSES.  All threads of the workgroup must call (barriers inside).
 template <int H, typename RT, int NM>
-__device__ __forceinline__ void sweep6(float (&m)[NM][6], Smem<H, RT>& sm, bool valid, int j, int c) {
+__device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool valid, int j, int c) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     if (valid) {
@@ -123,16 +124,16 @@ __device__ __forceinline__ void sweep6(float (&m)[NM][6], Smem<H, RT>& sm, bool 
     if (valid) {
 #pragma unroll
       for (int q = 0; q < NM; ++q) {
-        float col[6];
+        double col[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) col[b] = sm.ex[j][q][b];
-        const float pinv = 1.0f / col[k];
+        const double pinv = 1.0 / col[k];
         const bool isp = (c == k);
-        const float t = isp ? -pinv : m[q][k] * pinv;
+        const double t = isp ? -pinv : m[q][k] * pinv;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           if (b == k) continue;
-          m[q][b] = isp ? col[b] * pinv : fmaf(-t, col[b], m[q][b]);
+          m[q][b] = isp ? col[b] * pinv : fma(-t, col[b], m[q][b]);
         }
         m[q][k] = t;            // pivot lane: -1/p ; others: a_ik / p
       }
@@ -321,7 +322,7 @@ solve_kernel(const DevParams P, const int B,
             RT s = 0;
 #pragma unroll
             for (int q = 0; q < 3; ++q) s += (sm.Pre[i][3 * a + q] - sm.Pre[j2][3 * a + q]) * sm.Iw[j2][3 * q + b];
-            sm.Me[idx][3 * a + b] = dt * dt * s;
+            sm.Me[idx][3 * a + b] = (float)(dt * dt * s);
           }
       }
   }
@@ -344,13 +345,13 @@ solve_kernel(const DevParams P, const int B,
         RT acc[3] = {0, 0, 0};
 #pragma unroll 1
         for (int i = mx + 1; i < H; ++i) {
-          const RT* m1 = sm.Me[pair_index(i, j)];
-          const RT* m2 = sm.Me[pair_index(i, j2)];
+          const float* m1 = sm.Me[pair_index(i, j)];
+          const float* m2 = sm.Me[pair_index(i, j2)];
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
-            const RT u = m1[3 * q + a] * (RT)P.Q[q];
+            const RT u = (RT)m1[3 * q + a] * (RT)P.Q[q];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) acc[b] += u * m2[3 * q + b];
+            for (int b = 0; b < 3; ++b) acc[b] += u * (RT)m2[3 * q + b];
           }
         }
         const RT cnt = (RT)(H - mx);
@@ -368,9 +369,9 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll 1
       for (int i = j; i < H; ++i) {
         if (i > j) {
-          const RT* m1 = sm.Me[pair_index(i, j)];
+          const float* m1 = sm.Me[pair_index(i, j)];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) s += m1[3 * q + a] * (RT)P.Q[q] * sm.err[i][q];
+          for (int q = 0; q < 3; ++q) s += (RT)m1[3 * q + a] * (RT)P.Q[q] * sm.err[i][q];
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) s += nw[q] * sm.err[i][6 + q];
@@ -451,20 +452,21 @@ solve_kernel(const DevParams P, const int B,
   float Lcol[2][6];                           // L[j][f][i][c] for beta
 
   auto factor = [&]() {
+    // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
     // D_f = 2R + A' diag(rv) A, row c of both feet
     if (valid) {
       sm.rvg[j][0][c] = rvg[0];
       sm.rvg[j][1][c] = rvg[1];
     }
     __syncthreads();
-    float m3[3][6];                            // rows of D0, D1, Ka
-    float Tm[6][6];                            // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
+    double m3[3][6];                           // rows of D0, D1, Ka -> their inverses
+    double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
     {
-      const float dr[3] = {rf[0][0] - rf[1][0], rf[0][1] - rf[1][1], rf[0][2] - rf[1][2]};
+      const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
 #pragma unroll
       for (int p = 0; p < 6; ++p)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) Tm[p][q] = (p == q) ? 1.f : 0.f;
+        for (int q = 0; q < 6; ++q) Tm[p][q] = (p == q) ? 1.0 : 0.0;
       Tm[3][1] = -dr[2]; Tm[3][2] = dr[1];
       Tm[4][0] = dr[2];  Tm[4][2] = -dr[0];
       Tm[5][0] = -dr[1]; Tm[5][1] = dr[0];
@@ -476,10 +478,10 @@ solve_kernel(const DevParams P, const int B,
         general_rows(muf[f], ey, ez, lh, lt, G);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          float s = 0.f;
+          double s = 0.0;
 #pragma unroll
-          for (int r = 0; r < 6; ++r) s = fmaf(sm.rvg[j][f][r] * gcol[f][r], G[r][b], s);
-          m3[f][b] = s + ((b == c) ? (R2v[f] + rvb[f]) : 0.f);
+          for (int r = 0; r < 6; ++r) s = fma((double)sm.rvg[j][f][r] * (double)gcol[f][r], (double)G[r][b], s);
+          m3[f][b] = s + ((b == c) ? ((double)R2v[f] + (double)rvb[f]) : 0.0);
         }
 #pragma unroll
         for (int b = 0; b < 6; ++b) (f == 0 ? sm.M0 : sm.M1)[j][c][b] = m3[f][b];
@@ -487,24 +489,24 @@ solve_kernel(const DevParams P, const int B,
     }
     __syncthreads();
     if (valid) {                               // Ka = D0 + T' D1 T, row c
-      float yq[6];
+      double yq[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
-        float s = 0.f;
+        double s = 0.0;
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
-          float tpc = 0.f;
+          double tpc = 0.0;
 #pragma unroll
           for (int cc = 0; cc < 6; ++cc) tpc = (cc == c) ? Tm[p][cc] : tpc;
-          s = fmaf(tpc, sm.M1[j][p][q], s);
+          s = fma(tpc, sm.M1[j][p][q], s);
         }
         yq[q] = s;
       }
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        float s = m3[0][b];
+        double s = m3[0][b];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s = fmaf(yq[q], Tm[q][b], s);
+        for (int q = 0; q < 6; ++q) s = fma(yq[q], Tm[q][b], s);
         m3[2][b] = s;
       }
     }
@@ -516,96 +518,97 @@ solve_kernel(const DevParams P, const int B,
     }
     __syncthreads();
     // E = sum_f W_f D_f^-1 W_f',  W_f = [[r_f]x, I; I, 0]
-    float e1[1][6];
-    float Wm[2][6][6];
+    double e1[1][6];
+    double Wm[2][6][6];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
 #pragma unroll
       for (int p = 0; p < 6; ++p)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) Wm[f][p][q] = 0.f;
+        for (int q = 0; q < 6; ++q) Wm[f][p][q] = 0.0;
       Wm[f][0][1] = -rf[f][2]; Wm[f][0][2] = rf[f][1];
       Wm[f][1][0] = rf[f][2];  Wm[f][1][2] = -rf[f][0];
       Wm[f][2][0] = -rf[f][1]; Wm[f][2][1] = rf[f][0];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { Wm[f][a][3 + a] = 1.f; Wm[f][3 + a][a] = 1.f; }
+      for (int a = 0; a < 3; ++a) { Wm[f][a][3 + a] = 1.0; Wm[f][3 + a][a] = 1.0; }
     }
     if (valid) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) e1[0][b] = 0.f;
+      for (int b = 0; b < 6; ++b) e1[0][b] = 0.0;
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        float yq[6];
+        double yq[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          float s = 0.f;
+          double s = 0.0;
 #pragma unroll
           for (int p = 0; p < 6; ++p) {
-            float wcp = 0.f;
+            double wcp = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 6; ++cc) wcp = (cc == c) ? Wm[f][cc][p] : wcp;
-            s = fmaf(wcp, (f == 0 ? sm.M0 : sm.M1)[j][p][q], s);
+            s = fma(wcp, (f == 0 ? sm.M0 : sm.M1)[j][p][q], s);
           }
           yq[q] = s;
         }
 #pragma unroll
         for (int b = 0; b < 6; ++b)
 #pragma unroll
-          for (int q = 0; q < 6; ++q) e1[0][b] = fmaf(yq[q], Wm[f][b][q], e1[0][b]);
+          for (int q = 0; q < 6; ++q) e1[0][b] = fma(yq[q], Wm[f][b][q], e1[0][b]);
       }
     }
+    __syncthreads();                           // M0 (D0^-1) reads done: its slot now receives F
     sweep6<H, RT, 1>(e1, sm, valid, j, c);     // -> F = E^-1
     if (valid) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.F[j][c][b] = e1[0][b];
+      for (int b = 0; b < 6; ++b) sm.M0[j][c][b] = e1[0][b];
     }
     __syncthreads();
     if (valid) {
       // L_f = D_f^-1 W_f' F, row c (variable c of foot f)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        float xq[6];                           // (D_f^-1 W_f')[c][p] = sum_q Dinv[c][q] W[p][q]
+        double xq[6];                          // (D_f^-1 W_f')[c][p] = sum_q Dinv[c][q] W[p][q]
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
-          float s = 0.f;
+          double s = 0.0;
 #pragma unroll
-          for (int q = 0; q < 6; ++q) s = fmaf(m3[f][q], Wm[f][p][q], s);
+          for (int q = 0; q < 6; ++q) s = fma(m3[f][q], Wm[f][p][q], s);
           xq[p] = s;
         }
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          float s = 0.f;
+          double s = 0.0;
 #pragma unroll
-          for (int p = 0; p < 6; ++p) s = fmaf(xq[p], sm.F[j][p][b], s);
-          sm.L[j][f][c][b] = s;
+          for (int p = 0; p < 6; ++p) s = fma(xq[p], sm.M0[j][p][b], s);
+          sm.L[j][f][c][b] = (float)s;
         }
       }
       // Na = N Ka^-1 N', N_0 = I, N_1 = -T
-      float kt[6];                             // (Ka^-1 T')[c][b]
-      float tk[6];                             // (T Ka^-1)[c][b]
+      double kt[6];                            // (Ka^-1 T')[c][b]
+      double tk[6];                            // (T Ka^-1)[c][b]
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        float s = 0.f, s2 = 0.f;
+        double s = 0.0, s2 = 0.0;
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          s = fmaf(m3[2][q], Tm[b][q], s);
-          float tcq = 0.f;
+          s = fma(m3[2][q], Tm[b][q], s);
+          double tcq = 0.0;
 #pragma unroll
           for (int cc = 0; cc < 6; ++cc) tcq = (cc == c) ? Tm[cc][q] : tcq;
-          s2 = fmaf(tcq, sm.M2[j][q][b], s2);
+          s2 = fma(tcq, sm.M2[j][q][b], s2);
         }
         kt[b] = s;
         tk[b] = s2;
       }
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        sm.Na[j][0][c][b] = m3[2][b];
-        sm.Na[j][0][c][6 + b] = -kt[b];
-        sm.Na[j][1][c][b] = -tk[b];
-        float s = 0.f;
+        sm.Na[j][0][c][b] = (float)m3[2][b];
+        sm.Na[j][0][c][6 + b] = (float)(-kt[b]);
+        sm.Na[j][1][c][b] = (float)(-tk[b]);
+        double s = 0.0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s = fmaf(tk[q], Tm[b][q], s);
-        sm.Na[j][1][c][6 + b] = s;
+        for (int q = 0; q < 6; ++q) s = fma(tk[q], Tm[b][q], s);
+        sm.Na[j][1][c][6 + b] = (float)s;
       }
     }
     __syncthreads();
@@ -624,7 +627,7 @@ solve_kernel(const DevParams P, const int B,
       for (int j2 = 0; j2 < H; ++j2) {
         if (j2 == j) {
 #pragma unroll
-          for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] += sm.F[j][c][b];
+          for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] += (float)sm.M0[j][c][b];
         }
       }
 #pragma unroll
@@ -850,8 +853,10 @@ solve_kernel(const DevParams P, const int B,
         for (int f = 0; f < 2; ++f) {
           const bool actb = (zb[f] <= (RT)lb[f] || zb[f] >= (RT)ub[f]) && yb[f] != (RT)0;
           const bool actg = (zg[f] >= (RT)0) && yg[f] != (RT)0;
-          nb[f] = eqb[f] ? P.rho_eq : (actb ? (c < 3 ? P.rho_hi_f : P.rho_hi_m) : P.rho_lo);
-          ng[f] = actg ? (c < 4 ? P.rho_hi_f : P.rho_hi_m) : P.rho_lo;
+          // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
+          const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+          nb[f] = eqb[f] ? P.rho_eq : (actb ? fminf(rvb[f] * P.kappa, hib) : fmaxf(rvb[f] / P.kappa, P.rho_lo));
+          ng[f] = actg ? fminf(rvg[f] * P.kappa, hig) : fmaxf(rvg[f] / P.kappa, P.rho_lo);
           changed |= (nb[f] != rvb[f]) | (ng[f] != rvg[f]);
         }
       }
@@ -907,8 +912,8 @@ solve_kernel(const DevParams P, const int B,
         for (int j2 = 0; j2 <= i; ++j2) {
           const RT t3[3] = {sm.bw[6 * j2], sm.bw[6 * j2 + 1], sm.bw[6 * j2 + 2]};
           if (j2 < i) {
-            const RT* m1 = sm.Me[pair_index(i, j2)];
-            e += m1[3 * a] * t3[0] + m1[3 * a + 1] * t3[1] + m1[3 * a + 2] * t3[2];
+            const float* m1 = sm.Me[pair_index(i, j2)];
+            e += (RT)m1[3 * a] * t3[0] + (RT)m1[3 * a + 1] * t3[1] + (RT)m1[3 * a + 2] * t3[2];
           }
           w += dt * (sm.Iw[j2][3 * a] * t3[0] + sm.Iw[j2][3 * a + 1] * t3[1] + sm.Iw[j2][3 * a + 2] * t3[2]);
         }

@@ -63,9 +63,11 @@ typedef struct bmpc_params {
   /* solver (ADMM with active-set adaptive penalties) */
   double rho;                /* initial penalty on every row */
   double rho_eq_scale;       /* multiplier for rows with l == u (pinned variables) */
-  double rho_lo;             /* penalty of rows classified inactive */
-  double rho_hi_f;           /* penalty of active force-like rows (force box, friction) */
-  double rho_hi_m;           /* penalty of active moment-like rows (moment box, line-foot) */
+  double rho_lo;             /* floor of the per-row penalties */
+  double rho_hi_f;           /* ceiling for force-like rows (force box, friction) */
+  double rho_hi_m;           /* ceiling for moment-like rows (moment box, line-foot) */
+  double kappa;              /* per re-classification a row's penalty moves by this factor: up
+                                (towards its ceiling) if the row is active, down (towards rho_lo) if not */
   double alpha;              /* over-relaxation */
   double eps_pri, eps_dua;   /* relative stopping tolerances */
   int32_t max_iter;

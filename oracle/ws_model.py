@@ -47,19 +47,23 @@ class Params:
         self.tau_max = np.asarray(biped.tau_max, float).reshape(3)
         self.tau_min = np.asarray(biped.tau_min, float).reshape(3)
         # solver
-        self.rho = 0.01
+        self.rho = 0.1
         self.rho_eq_scale = 1e3
         self.rho_lo = 3e-4
-        self.rho_hi_f = 0.1
-        self.rho_hi_m = 1.0
+        self.rho_hi_f = 1.0
+        self.rho_hi_m = 100.0
         self.adapt_start = 20
         self.adapt_every = 10
+        self.adapt_growth = 1.0
+        self.use_fraction = False
+        self.blocks_hi = True
+        self.kappa = 10.0
         self.alpha = 1.6
         self.max_iter = 400
         self.check_every = 5
-        self.eps_pri = 3e-7
-        self.eps_dua = 3e-7
-        self.max_refactor = 12
+        self.eps_pri = 1e-6
+        self.eps_dua = 1e-6
+        self.max_refactor = 40
 
 
 def _skew(v):
@@ -189,21 +193,25 @@ def constraint_blocks(P, x_fb, contact, mu, dt_):
     return A, l, u
 
 
-def _factor(P, Gt, A, rv, Rblk, Wf, Nf, dtp):
-    """Everything that depends on the per-row penalties rv: L, Na (block diagonal) and V (dense)."""
+def _factor(P, Gt, A, rv, Rblk, Wf, Nf, dtp, blk=None):
+    """Everything that depends on the per-row penalties rv: L, Na (block diagonal) and V (dense).
+    blk: arithmetic of the 6x6 block algebra (default dtp); the dense sweep is always dtp."""
     B, h = rv.shape[0], P.h
-    D = np.einsum("bhfri,bhfr,bhfrj->bhfij", A, rv, A)
-    D = D + (Rblk[None, None, :, :, None] * np.eye(6, dtype=dtp))
-    Dinv = np.linalg.inv(D).astype(dtp)
-    E = np.einsum("bhfij,bhfjk,bhflk->bhil", Wf, Dinv, Wf)
-    F = np.linalg.inv(E).astype(dtp)
-    L = np.einsum("bhfij,bhfkj,bhkl->bhfil", Dinv, Wf, F)                 # (B,h,2,6,6): D^-1 W' F
-    Ka = np.einsum("bhfij,bhfik,bhfkl->bhjl", Nf, D, Nf)
-    Kainv = np.linalg.inv(Ka).astype(dtp)
-    Na = np.einsum("bhfij,bhjk,bhglk->bhfigl", Nf, Kainv, Nf)             # (B,h,f,6,g,6)
-    K = Gt.copy()
+    bt = np.dtype(blk or dtp)
+    A_, rv_, Wf_, Nf_ = A.astype(bt), rv.astype(bt), Wf.astype(bt), Nf.astype(bt)
+    D = np.einsum("bhfri,bhfr,bhfrj->bhfij", A_, rv_, A_)
+    D = D + (Rblk.astype(bt)[None, None, :, :, None] * np.eye(6, dtype=bt))
+    Dinv = np.linalg.inv(D)
+    E = np.einsum("bhfij,bhfjk,bhflk->bhil", Wf_, Dinv, Wf_)
+    F = np.linalg.inv(E)
+    L = np.einsum("bhfij,bhfkj,bhkl->bhfil", Dinv, Wf_, F).astype(dtp)    # (B,h,2,6,6): D^-1 W' F
+    Ka = np.einsum("bhfij,bhfik,bhfkl->bhjl", Nf_, D, Nf_)
+    Kainv = np.linalg.inv(Ka)
+    Na = np.einsum("bhfij,bhjk,bhglk->bhfigl", Nf_, Kainv, Nf_).astype(dtp)  # (B,h,f,6,g,6)
+    K = Gt.astype(dtp).copy()
+    F32 = F.astype(dtp)
     for j in range(h):
-        K[:, 6 * j:6 * j + 6, 6 * j:6 * j + 6] += F[:, j]
+        K[:, 6 * j:6 * j + 6, 6 * j:6 * j + 6] += F32[:, j]
     V = np.linalg.inv(K).astype(dtp)
     return L, Na, V
 
@@ -253,10 +261,12 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     Nf[:, :, 0] = np.eye(6, dtype=dtp)
     Nf[:, :, 1] = -np.eye(6, dtype=dtp)
     Nf[:, :, 1, 3:6, 0:3] = -_skew(r[:, :, 0] - r[:, :, 1])
-    fac = lambda rv_: _factor(P, Gt.astype(pdt), A.astype(pdt), rv_.astype(pdt), Rblk.astype(pdt),
-                              Wf.astype(pdt), Nf.astype(pdt), pdt)
+    fac = lambda rv_: _factor(P, Gt, A, rv_, Rblk, Wf, Nf, pdt, blk=(rdt if P.blocks_hi else pdt))
     L, Na, V = fac(rv)
     n_factor = np.ones(B, int)
+    next_adapt, gap = P.adapt_start, P.adapt_every
+    cnt_act = np.zeros(rv.shape, int)
+    cnt_len = 0
     alpha = rdt.type(P.alpha)
     x = np.zeros((B, h, 2, 6), rdt)
     z = np.zeros((B, h, 2, 12), rdt)
@@ -304,9 +314,24 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
         y = np.where(keep, yn, y)
         if not active.any():
             break
-        if P.adapt_every and (it + 1) >= P.adapt_start and (it + 1 - P.adapt_start) % P.adapt_every == 0:
+        cnt_act += (((z <= lr) | (z >= ur)) & (y != 0))
+        cnt_len += 1
+        if P.adapt_every and (it + 1) == next_adapt:
+            gap = max(int(round(gap * P.adapt_growth)), 1)
+            next_adapt += gap
             act = ((z <= lr) | (z >= ur)) & (y != 0)
-            rnew = np.where(eq, rho_eq, np.where(act, hi, dt_(P.rho_lo))).astype(dtp)
+            if P.use_fraction:
+                full = cnt_act >= cnt_len
+                none = cnt_act == 0
+                rnew = np.where(eq, rho_eq, np.where(full, hi, np.where(none, dt_(P.rho_lo), rho0))).astype(dtp)
+            elif P.kappa:
+                up = np.minimum(rv * dt_(P.kappa), hi)
+                dn = np.maximum(rv / dt_(P.kappa), dt_(P.rho_lo))
+                rnew = np.where(eq, rho_eq, np.where(act, up, dn)).astype(dtp)
+            else:
+                rnew = np.where(eq, rho_eq, np.where(act, hi, dt_(P.rho_lo))).astype(dtp)
+            cnt_act[:] = 0
+            cnt_len = 0
             changed = (rnew != rv).reshape(B, -1).any(1) & active & (n_factor <= P.max_refactor)
             if changed.any():
                 rv = np.where(changed[:, None, None, None], rnew, rv)
