@@ -15,7 +15,7 @@ EXPORTS = (
     "bmpc_abi_version", "bmpc_last_error", "bmpc_supported_horizon", "bmpc_default_params",
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
     "bmpc_solve_batch", "bmpc_solve_batch_device", "bmpc_synchronize",
-    "bmpc_debug_assemble", "bmpc_last_kernel_ms",
+    "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
 )
 
 
@@ -70,6 +70,7 @@ def load():
     lib.bmpc_solve_batch_device.argtypes = [vp, ip] + ptrs14 + [vp]
     lib.bmpc_synchronize.argtypes = [vp]
     lib.bmpc_debug_assemble.argtypes = [vp, ip] + [vp] * 10
+    lib.bmpc_debug_set_profile.argtypes = [vp, vp]
     lib.bmpc_last_kernel_ms.argtypes = [vp, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)

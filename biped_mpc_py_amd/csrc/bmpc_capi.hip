@@ -103,6 +103,7 @@ struct bmpc_handle_s {
   DevBuf<uint8_t> contact;
   DevBuf<int32_t> phase, iters, status, nfactor;
   DevBuf<double> dbg;
+  long long* prof_dev = nullptr;   // optional cycle-stamp buffer (bmpc_debug_set_profile)
 };
 
 namespace {
@@ -238,7 +239,7 @@ int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float
   if (B == 0) return BMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
-  bmpc::DebugOut dbg = {nullptr, nullptr, nullptr, nullptr, 0};
+  bmpc::DebugOut dbg = {nullptr, nullptr, nullptr, nullptr, h->prof_dev, 0};
   HIP_TRY(hipEventRecord(h->ev0, st));
   rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st);
   if (rc != BMPC_OK) return rc;
@@ -311,7 +312,7 @@ int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* fo
   HIP_TRY(hipMemcpyAsync(h->phase.p, phase, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
   if (x_cmd) HIP_TRY(hipMemcpyAsync(h->x_cmd.p, x_cmd, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
   if (mu) HIP_TRY(hipMemcpyAsync(h->mu.p, mu, n * H * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-  bmpc::DebugOut dbg = {h->dbg.p + o_xr, h->dbg.p + o_fr, h->dbg.p + o_gt, h->dbg.p + o_qt, 1};
+  bmpc::DebugOut dbg = {h->dbg.p + o_xr, h->dbg.p + o_fr, h->dbg.p + o_gt, h->dbg.p + o_qt, nullptr, 1};
   rc = launch(h, B, h->x_fb.p, h->foot.p, h->contact.p, h->phase.p, x_cmd ? h->x_cmd.p : nullptr,
               mu ? h->mu.p : nullptr, h->controls.p, nullptr, nullptr, nullptr, nullptr, nullptr, dbg, st);
   if (rc != BMPC_OK) return rc;
@@ -320,6 +321,12 @@ int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* fo
   if (Gt) HIP_TRY(hipMemcpyAsync(Gt, h->dbg.p + o_gt, n * NW * NW * sizeof(double), hipMemcpyDeviceToHost, st));
   if (qt) HIP_TRY(hipMemcpyAsync(qt, h->dbg.p + o_qt, n * NW * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
+int bmpc_debug_set_profile(bmpc_handle h, long long* device_buf) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  h->prof_dev = device_buf;
   return BMPC_OK;
 }
 

@@ -39,6 +39,7 @@ struct DebugOut {            // all nullable, fp64, device pointers
   double* foot_ref;          // [B][H][6]
   double* Gt;                // [B][6H][6H]
   double* qt;                // [B][6H]
+  long long* prof;           // [B][8] cycle stamps (diagnostic builds / tests only)
   int assemble_only;
 };
 
@@ -71,6 +72,8 @@ struct alignas(16) Smem {
   RT Pre[H][9];              // prefix sums of R_inv
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
   RT err[H][12];             // free response - reference
+  RT xref[H][12];            // x_ref[:, j]
+  RT fref[H][6];             // foot_ref[:, j]
   float Me[Dims<H>::NPAIR > 0 ? Dims<H>::NPAIR : 1][9];   // dt^2 (P_i - P_j) Iw_j, i > j (data: f32)
   // factor scratch
   float rvg[H][2][6];
@@ -154,15 +157,6 @@ __device__ __forceinline__ float min_rt(float a, float b) { return fminf(a, b); 
 __device__ __forceinline__ double max_rt(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float max_rt(float a, float b) { return fmaxf(a, b); }
 
-// a[idx] for a runtime idx without demoting the array to scratch
-template <int N, typename T>
-__device__ __forceinline__ T pick(const T (&a)[N], int idx) {
-  T v = a[0];
-#pragma unroll
-  for (int q = 1; q < N; ++q) v = (q == idx) ? a[q] : v;
-  return v;
-}
-
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* o) {
   o[0] = a[1] * b[2] - a[2] * b[1];
@@ -205,11 +199,22 @@ solve_kernel(const DevParams P, const int B,
 
   const int inst = blockIdx.x;
   if (inst >= B) return;
+  long long t_start = 0, t_setup = 0, t_blocks = 0, t_sweep = 0, t_mark = 0;
+  if (dbg.prof) t_start = clock64();
   const int l = threadIdx.x;
   const bool valid = l < NW;
   const int j = valid ? l / 6 : 0;
   const int c = valid ? l % 6 : 0;
   const RT dt = (RT)P.dt;
+  // 0/1 masks of this lane's component: runtime picks are done arithmetically (select chains over
+  // register arrays get demoted to scratch by the compiler)
+  float mkf[6];
+  double mkd[6];
+  RT mk3[3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { mkf[k] = (c == k) ? 1.f : 0.f; mkd[k] = (c == k) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mk3[k] = (c % 3 == k) ? (RT)1 : (RT)0;
 
   // ------------------------------------------------------------------ A. references, step data
   RT xfb[12], xc[12];
@@ -241,11 +246,12 @@ solve_kernel(const DevParams P, const int B,
       fr[0] = fx; fr[1] = fy; fr[2] = 0; fr[3] = fx; fr[4] = fy; fr[5] = 0;
     }
   }
-  if (dbg.x_ref && valid) {
-    dbg.x_ref[((size_t)inst * H + j) * 12 + c] = (double)pick(xr, c);
-    dbg.x_ref[((size_t)inst * H + j) * 12 + 6 + c] = (double)pick(xr, 6 + c);
+  if (valid && c == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) sm.xref[j][i] = xr[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sm.fref[j][i] = fr[i];
   }
-  if (dbg.foot_ref && valid) dbg.foot_ref[((size_t)inst * H + j) * 6 + c] = (double)pick(fr, c);
 
   RT Pj[9];                                    // prefix sum of R_inv up to this lane's step
   {
@@ -303,10 +309,19 @@ solve_kernel(const DevParams P, const int B,
     }
     e12[5] -= (RT)P.g * dt * dt * (RT)j * j1 / 2;
     e12[11] -= (RT)P.g * dt * j1;
-    sm.err[j][c] = pick(e12, c) - pick(xr, c);
-    sm.err[j][c + 6] = pick(e12, c + 6) - pick(xr, c + 6);
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) sm.err[j][i] = e12[i] - xr[i];
+    }
   }
   __syncthreads();
+  if (valid) {
+    if (dbg.x_ref) {
+      dbg.x_ref[((size_t)inst * H + j) * 12 + c] = (double)sm.xref[j][c];
+      dbg.x_ref[((size_t)inst * H + j) * 12 + 6 + c] = (double)sm.xref[j][6 + c];
+    }
+    if (dbg.foot_ref) dbg.foot_ref[((size_t)inst * H + j) * 6 + c] = (double)sm.fref[j][c];
+  }
   // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2
   {
     int idx = 0;
@@ -399,6 +414,7 @@ solve_kernel(const DevParams P, const int B,
     if (dbg.qt) dbg.qt[(size_t)inst * NW + l] = (double)qt;
   }
   if (dbg.assemble_only) return;
+  if (dbg.prof) t_setup = clock64() - t_start;
 
   // ------------------------------------------------------------------ C. constraint data
   float ey[3], ez[3];                         // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
@@ -430,14 +446,14 @@ solve_kernel(const DevParams P, const int B,
     for (int b = 0; b < 6; ++b) {
       float gr = 0.f;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) gr = (r == c) ? G[r][b] : gr;   // runtime c: select row c
+      for (int r = 0; r < 6; ++r) gr = fmaf(mkf[r], G[r][b], gr);   // row c
       grow[f][b] = gr;
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       float gc = 0.f;
 #pragma unroll
-      for (int b = 0; b < 6; ++b) gc = (b == c) ? G[r][b] : gc;
+      for (int b = 0; b < 6; ++b) gc = fmaf(mkf[b], G[r][b], gc);   // column c
       gcol[f][r] = gc;
     }
 #pragma unroll
@@ -448,10 +464,14 @@ solve_kernel(const DevParams P, const int B,
   float rvb[2], rvg[2];                       // penalties of this lane's box rows / general rows
 #pragma unroll
   for (int f = 0; f < 2; ++f) { rvb[f] = eqb[f] ? P.rho_eq : P.rho; rvg[f] = P.rho; }
+  RT irvb[2], irvg[2];                        // reciprocals (refreshed with the penalties)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) { irvb[f] = (RT)1 / (RT)rvb[f]; irvg[f] = (RT)1 / (RT)rvg[f]; }
   float Vrow[NW];                             // row l of -(Gt + F)^-1 after the sweep
   float Lcol[2][6];                           // L[j][f][i][c] for beta
 
   auto factor = [&]() {
+    if (dbg.prof) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
     // D_f = 2R + A' diag(rv) A, row c of both feet
     if (valid) {
@@ -471,6 +491,14 @@ solve_kernel(const DevParams P, const int B,
       Tm[4][0] = dr[2];  Tm[4][2] = -dr[0];
       Tm[5][0] = -dr[1]; Tm[5][1] = dr[0];
     }
+    double Tcol[6], Trow[6];                   // T[:, c] and T[c, :]
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) { a1 = fma(mkd[cc], Tm[p][cc], a1); a2 = fma(mkd[cc], Tm[cc][p], a2); }
+      Tcol[p] = a1; Trow[p] = a2;
+    }
     if (valid) {
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
@@ -481,7 +509,7 @@ solve_kernel(const DevParams P, const int B,
           double s = 0.0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) s = fma((double)sm.rvg[j][f][r] * (double)gcol[f][r], (double)G[r][b], s);
-          m3[f][b] = s + ((b == c) ? ((double)R2v[f] + (double)rvb[f]) : 0.0);
+          m3[f][b] = fma(mkd[b], (double)R2v[f] + (double)rvb[f], s);
         }
 #pragma unroll
         for (int b = 0; b < 6; ++b) (f == 0 ? sm.M0 : sm.M1)[j][c][b] = m3[f][b];
@@ -494,12 +522,7 @@ solve_kernel(const DevParams P, const int B,
       for (int q = 0; q < 6; ++q) {
         double s = 0.0;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-          double tpc = 0.0;
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc) tpc = (cc == c) ? Tm[p][cc] : tpc;
-          s = fma(tpc, sm.M1[j][p][q], s);
-        }
+        for (int p = 0; p < 6; ++p) s = fma(Tcol[p], sm.M1[j][p][q], s);
         yq[q] = s;
       }
 #pragma unroll
@@ -532,6 +555,16 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int a = 0; a < 3; ++a) { Wm[f][a][3 + a] = 1.0; Wm[f][3 + a][a] = 1.0; }
     }
+    double Wrow[2][6];                         // W_f[c, :]
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        double a1 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) a1 = fma(mkd[cc], Wm[f][cc][p], a1);
+        Wrow[f][p] = a1;
+      }
     if (valid) {
 #pragma unroll
       for (int b = 0; b < 6; ++b) e1[0][b] = 0.0;
@@ -542,12 +575,7 @@ solve_kernel(const DevParams P, const int B,
         for (int q = 0; q < 6; ++q) {
           double s = 0.0;
 #pragma unroll
-          for (int p = 0; p < 6; ++p) {
-            double wcp = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) wcp = (cc == c) ? Wm[f][cc][p] : wcp;
-            s = fma(wcp, (f == 0 ? sm.M0 : sm.M1)[j][p][q], s);
-          }
+          for (int p = 0; p < 6; ++p) s = fma(Wrow[f][p], (f == 0 ? sm.M0 : sm.M1)[j][p][q], s);
           yq[q] = s;
         }
 #pragma unroll
@@ -592,10 +620,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
           s = fma(m3[2][q], Tm[b][q], s);
-          double tcq = 0.0;
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc) tcq = (cc == c) ? Tm[cc][q] : tcq;
-          s2 = fma(tcq, sm.M2[j][q][b], s2);
+          s2 = fma(Trow[q], sm.M2[j][q][b], s2);
         }
         kt[b] = s;
         tk[b] = s2;
@@ -612,6 +637,7 @@ solve_kernel(const DevParams P, const int B,
       }
     }
     __syncthreads();
+    if (dbg.prof) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
     // K' row = Gt row + F row on the own step; then symmetric sweep with a rotating register file:
     // at step k register r holds column (r + k) mod NW, so the pivot column is always register 0.
     if (valid) {
@@ -619,43 +645,63 @@ solve_kernel(const DevParams P, const int B,
       for (int q = 0; q < NW; ++q) {
         const int j2 = q / 6, b = q % 6;
         float v;
-        if (c < 3) v = (b < 3) ? Grow[3 * j2 + b] : 0.f;
-        else v = (b == c) ? Grow[j2] : 0.f;
+        if (c < 3) v = (b < 3) ? Grow[3 * j2 + (b < 3 ? b : 0)] : 0.f;
+        else v = mkf[b] * Grow[j2];
         Vrow[q] = v;
       }
+      float fv[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) fv[b] = (float)sm.M0[j][c][b];
 #pragma unroll
       for (int j2 = 0; j2 < H; ++j2) {
-        if (j2 == j) {
+        const float mj = (j2 == j) ? 1.f : 0.f;
 #pragma unroll
-          for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] += (float)sm.M0[j][c][b];
-        }
+        for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] = fmaf(mj, fv[b], Vrow[6 * j2 + b]);
       }
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int i = 0; i < 6; ++i) Lcol[f][i] = sm.L[j][f][i][c];
     }
+    // Groups of U steps are unrolled so the pivot column sits in the static register u; the register
+    // file is rotated by U once per group.  Pivot lane: row = column / p; other lanes: row -= (a_ik/p) * pivot row.
+    constexpr int U = 6;
+    static_assert(NW % U == 0 && U % 2 == 0, "sweep group must divide 6H and be even");
 #pragma unroll 1
-    for (int k = 0; k < NW; ++k) {
-      float* buf = sm.piv[k & 1];
-      if (valid) {
-        int pos = l - k;
-        pos += (pos < 0) ? NW : 0;
-        buf[pos] = Vrow[0];
-      }
-      __syncthreads();
-      if (valid) {
-        const float pinv = 1.0f / buf[0];
-        const bool isp = (l == k);
-        const float t = isp ? -pinv : Vrow[0] * pinv;
+    for (int k0 = 0; k0 < NW; k0 += U) {
 #pragma unroll
-        for (int r = 1; r < NW; ++r) {
-          const float base = isp ? 0.f : Vrow[r];
-          Vrow[r - 1] = fmaf(-t, buf[r], base);
+      for (int u = 0; u < U; ++u) {
+        float* buf = sm.piv[u & 1];
+        if (valid) {
+          int pos = l - k0;
+          pos += (pos < 0) ? NW : 0;
+          buf[pos] = Vrow[u];
         }
-        Vrow[NW - 1] = t;
+        __syncthreads();
+        if (valid) {
+          const float ci = Vrow[u];
+          const float pinv = __builtin_amdgcn_rcpf(buf[u]);
+          const bool isp = (l == k0 + u);
+          // the pivot lane rebuilds its row from the published COLUMN (buf), which re-symmetrises the
+          // matrix at every pivot; scaling its own row instead lets f32 asymmetry grow and diverge
+          const float sc = isp ? 0.f : 1.f;
+          const float t = isp ? -pinv : ci * pinv;
+#pragma unroll
+          for (int r = 0; r < NW; ++r) Vrow[r] = fmaf(-t, buf[r], sc * Vrow[r]);
+          Vrow[u] = t;
+        }
+      }
+      if (valid) {                             // rotate left by U
+        float tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) tmp[u] = Vrow[u];
+#pragma unroll
+        for (int r = 0; r + U < NW; ++r) Vrow[r] = Vrow[r + U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) Vrow[NW - U + u] = tmp[u];
       }
     }
+    if (dbg.prof) t_sweep += clock64() - t_mark;
   };
 
   int nfac = 0;
@@ -700,10 +746,10 @@ solve_kernel(const DevParams P, const int B,
         cross3(r1, &xblk[1][0], t1);
         RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
                     t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
-        val = c == 0 ? v3[0] : (c == 1 ? v3[1] : v3[2]);
+        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       } else {
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
-        val = c == 3 ? v3[0] : (c == 4 ? v3[1] : v3[2]);
+        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
       sm.bw[l] = val;
     }
@@ -737,9 +783,9 @@ solve_kernel(const DevParams P, const int B,
           const RT rfd[3] = {sm.rr[j][f][0], sm.rr[j][f][1], sm.rr[j][f][2]};
           RT cr3[3];
           cross3(gt3, rfd, cr3);               // [r]x' g_tau = g_tau x r
-          wt = (c == 0 ? cr3[0] + gf3[0] : (c == 1 ? cr3[1] + gf3[1] : cr3[2] + gf3[2]));
+          wt = mk3[0] * (cr3[0] + gf3[0]) + mk3[1] * (cr3[1] + gf3[1]) + mk3[2] * (cr3[2] + gf3[2]);
         } else {
-          wt = (c == 3 ? gt3[0] : (c == 4 ? gt3[1] : gt3[2]));
+          wt = mk3[0] * gt3[0] + mk3[1] * gt3[1] + mk3[2] * gt3[2];
         }
         sm.r32[j][f][c] = (float)(r + wt);
       }
@@ -808,7 +854,7 @@ solve_kernel(const DevParams P, const int B,
         // box row
         {
           const RT zr = alpha * ztb + (1 - alpha) * zb[f];
-          const RT cand = zr + yb[f] / (RT)rvb[f];
+          const RT cand = zr + yb[f] * irvb[f];
           const RT zn = min_rt(max_rt(cand, (RT)lb[f]), (RT)ub[f]);
           yb[f] += (RT)rvb[f] * (zr - zn);
           zb[f] = zn;
@@ -818,7 +864,7 @@ solve_kernel(const DevParams P, const int B,
         // general row: l = -inf, u = 0
         {
           const RT zr = alpha * ztg + (1 - alpha) * zg[f];
-          const RT cand = zr + yg[f] / (RT)rvg[f];
+          const RT cand = zr + yg[f] * irvg[f];
           const RT zn = min_rt(cand, (RT)0);
           yg[f] += (RT)rvg[f] * (zr - zn);
           zg[f] = zn;
@@ -864,7 +910,10 @@ solve_kernel(const DevParams P, const int B,
       if (changed) {
         if (valid) {
 #pragma unroll
-          for (int f = 0; f < 2; ++f) { rvb[f] = nb[f]; rvg[f] = ng[f]; }
+          for (int f = 0; f < 2; ++f) {
+            rvb[f] = nb[f]; rvg[f] = ng[f];
+            irvb[f] = (RT)1 / (RT)nb[f]; irvg[f] = (RT)1 / (RT)ng[f];
+          }
         }
         need_factor = true;
       }
@@ -893,10 +942,10 @@ solve_kernel(const DevParams P, const int B,
         cross3(r1, &xblk[1][0], t1);
         RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
                     t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
-        val = c == 0 ? v3[0] : (c == 1 ? v3[1] : v3[2]);
+        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       } else {
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
-        val = c == 3 ? v3[0] : (c == 4 ? v3[1] : v3[2]);
+        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
       sm.bw[l] = val;
     }
@@ -917,8 +966,8 @@ solve_kernel(const DevParams P, const int B,
           }
           w += dt * (sm.Iw[j2][3 * a] * t3[0] + sm.Iw[j2][3 * a + 1] * t3[1] + sm.Iw[j2][3 * a + 2] * t3[2]);
         }
-        so[a] = (float)(e + pick(xr, a));
-        so[6 + a] = (float)(w + pick(xr, 6 + a));
+        so[a] = (float)(e + sm.xref[i][a]);
+        so[6 + a] = (float)(w + sm.xref[i][6 + a]);
       } else {
         const int a = c - 3;
         RT p = sm.err[i][3 + a], v = sm.err[i][9 + a];
@@ -929,11 +978,15 @@ solve_kernel(const DevParams P, const int B,
           p += kp * (RT)(i - j2) * fa;
           v += kvv * fa;
         }
-        so[3 + a] = (float)(p + pick(xr, 3 + a));
-        so[9 + a] = (float)(v + pick(xr, 9 + a));
+        so[3 + a] = (float)(p + sm.xref[i][3 + a]);
+        so[9 + a] = (float)(v + sm.xref[i][9 + a]);
       }
       if (c == 0) so[12] = 1.0f;
     }
+  }
+  if (dbg.prof && l == 0) {
+    long long* pr = dbg.prof + (size_t)inst * 8;
+    pr[0] = t_setup; pr[1] = t_blocks; pr[2] = t_sweep; pr[3] = clock64() - t_start; pr[4] = it; pr[5] = nfac;
   }
   if (l == 0) {
     if (iters_out) iters_out[inst] = it;

@@ -144,6 +144,11 @@ int bmpc_debug_assemble(bmpc_handle h, int B,
                         const int32_t* phase, const float* x_cmd, const float* mu,
                         double* x_ref, double* foot_ref, double* Gt, double* qt);
 
+/* Diagnostics: when device_buf (DEVICE pointer, [max_batch][8] int64) is non-NULL every later solve
+ * writes per-instance shader-clock stamps {setup, block algebra, dense sweeps, total, iters,
+ * factorisations, -, -}; NULL switches it off (default).  Costs a few s_memtime per phase. */
+int bmpc_debug_set_profile(bmpc_handle h, long long* device_buf);
+
 /* Time of the last bmpc_solve_batch* kernel launch on the handle's stream, measured with HIP
  * events around the launch (milliseconds); <0 if none.  Forces a stream synchronise. */
 int bmpc_last_kernel_ms(bmpc_handle h, float* ms);

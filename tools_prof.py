@@ -1,0 +1,25 @@
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0,'/root/repo')
+import biped_mpc_py_amd as bm
+from biped_mpc_py_amd import _lib
+from bench import synth
+B=int(sys.argv[1]) if len(sys.argv)>1 else 256
+h=10
+s=bm.BatchSolver(max_batch=B)
+x,f,c,p=synth(B,h,1)
+dev=torch.device('cuda',0)
+prof=torch.zeros((B,8),dtype=torch.int64,device=dev)
+_lib.check(s._lib.bmpc_debug_set_profile(s._h, prof.data_ptr()))
+tx,tf,tc,tp=[torch.from_numpy(a).to(dev) for a in (x,f,c,p)]
+st=torch.cuda.Stream()
+with torch.cuda.stream(st):
+    for _ in range(3):
+        s.solve_device(tx,tf,tc,tp)
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record(); s.solve_device(tx,tf,tc,tp); e1.record()
+torch.cuda.synchronize()
+pr=prof.cpu().numpy().astype(float)
+print('B',B,'kernel ms',e0.elapsed_time(e1))
+print('cycles mean: setup %.0f blocks %.0f sweeps %.0f total %.0f | iters %.1f nfac %.2f'%tuple(pr[:,:6].mean(0)))
+it=pr[:,3]-pr[:,0]-pr[:,1]-pr[:,2]
+print('iteration cycles per iter %.0f ; blocks per factor %.0f ; sweep per factor %.0f'%((it/pr[:,4]).mean(),(pr[:,1]/pr[:,5]).mean(),(pr[:,2]/pr[:,5]).mean()))
