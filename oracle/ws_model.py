@@ -61,8 +61,8 @@ class Params:
         self.alpha = 1.6
         self.max_iter = 400
         self.check_every = 5
-        self.eps_pri = 1e-6
-        self.eps_dua = 1e-6
+        self.eps_pri = 1e-7
+        self.eps_dua = 1e-7
         self.max_refactor = 40
 
 
