@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=64, help="instances for the CPU baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (1-GPU box, use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -111,11 +114,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import biped_mpc_py_amd as bm
 
@@ -123,8 +131,8 @@ def main():
     mpc = bm.MPC()
     cp = bm.pack_params(mpc, bm.Biped())
     if world > 1:                                   # C0: one parameter block for every rank
-        bm.sharding.broadcast_params(cp, src=0, device=dev)
-    solver = bm.BatchSolver(cparams=cp, device=local_rank, max_batch=B)
+        bm.sharding.broadcast_params(cp, src=0, device=coll_dev)
+    solver = bm.BatchSolver(cparams=cp, device=dev_index, max_batch=B)
     x_fb, foot, contact, phase = synth(B, H, seed=1 + 1000 * rank)   # seed 1 = config 2
     t_x, t_f = torch.from_numpy(x_fb).to(dev), torch.from_numpy(foot).to(dev)
     t_c, t_p = torch.from_numpy(contact).to(dev), torch.from_numpy(phase).to(dev)
@@ -162,7 +170,7 @@ def main():
         elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration over the timed region
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -56,6 +56,7 @@ struct alignas(16) Smem {
   static constexpr int NW = Dims<H>::NW;
   // iteration vectors
   RT xt[H][2][6];            // x tilde
+  RT xs[H][2][6];            // x (relaxed iterate); re-read per iteration instead of living in VGPRs
   RT wg[H][2][6];            // y + rho (A x - z) on the general rows
   RT bw[NW];                 // net wrench of x
   RT gb[NW];                 // wrench-space gradient Gt b + qt
@@ -468,7 +469,6 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
   for (int f = 0; f < 2; ++f) { irvb[f] = (RT)1 / (RT)rvb[f]; irvg[f] = (RT)1 / (RT)rvg[f]; }
   float Vrow[NW];                             // row l of -(Gt + F)^-1 after the sweep
-  float Lcol[2][6];                           // L[j][f][i][c] for beta
 
   auto factor = [&]() {
     if (dbg.prof) t_mark = clock64();
@@ -658,10 +658,6 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] = fmaf(mj, fv[b], Vrow[6 * j2 + b]);
       }
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Lcol[f][i] = sm.L[j][f][i][c];
     }
     // Groups of U steps are unrolled so the pivot column sits in the static register u; the register
     // file is rotated by U once per group.  Pivot lane: row = column / p; other lanes: row -= (a_ik/p) * pivot row.
@@ -679,15 +675,23 @@ solve_kernel(const DevParams P, const int B,
         }
         __syncthreads();
         if (valid) {
+          // fetch the whole pivot vector first (NW/4 back-to-back ds_read_b128, one wait), then compute:
+          // with one wave per SIMD nothing else hides the LDS latency
+          float pb[NW];
+#pragma unroll
+          for (int r = 0; r < NW; r += 4) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&buf[r]);
+            pb[r] = q4.x; pb[r + 1] = q4.y; pb[r + 2] = q4.z; pb[r + 3] = q4.w;
+          }
           const float ci = Vrow[u];
-          const float pinv = __builtin_amdgcn_rcpf(buf[u]);
+          const float pinv = __builtin_amdgcn_rcpf(pb[u]);
           const bool isp = (l == k0 + u);
           // the pivot lane rebuilds its row from the published COLUMN (buf), which re-symmetrises the
           // matrix at every pivot; scaling its own row instead lets f32 asymmetry grow and diverge
           const float sc = isp ? 0.f : 1.f;
           const float t = isp ? -pinv : ci * pinv;
 #pragma unroll
-          for (int r = 0; r < NW; ++r) Vrow[r] = fmaf(-t, buf[r], sc * Vrow[r]);
+          for (int r = 0; r < NW; ++r) Vrow[r] = fmaf(-t, pb[r], sc * Vrow[r]);
           Vrow[u] = t;
         }
       }
@@ -710,11 +714,7 @@ solve_kernel(const DevParams P, const int B,
   // ------------------------------------------------------------------ E. ADMM iterations
   RT xo[2] = {0, 0};                          // own variables
   RT zb[2] = {0, 0}, zg[2] = {0, 0}, yb[2] = {0, 0}, yg[2] = {0, 0};
-  RT xblk[2][6];                              // both foot blocks of this step (redundant per lane)
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int b = 0; b < 6; ++b) xblk[f][b] = 0;
+  if (valid) { sm.xs[j][0][c] = 0; sm.xs[j][1][c] = 0; }
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   float res_p = 0.f, res_s = 0.f;
@@ -729,6 +729,11 @@ solve_kernel(const DevParams P, const int B,
     // --- E1: row residuals w = y + rho (A x - z), net wrench of x
     RT wb[2];
     if (valid) {
+      RT xblk[2][6];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) xblk[f][b] = sm.xs[j][f][b];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         RT axg = 0;
@@ -800,7 +805,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           rj[f][i] = sm.r32[j][f][i];
-          s = fmaf(Lcol[f][i], rj[f][i], s);
+          s = fmaf(sm.L[j][f][i][c], rj[f][i], s);
         }
       sm.beta[l] = s;
     }
@@ -873,12 +878,12 @@ solve_kernel(const DevParams P, const int B,
         }
         rs = fmaxf(rs, fabsf((float)(xto[f] - xo[f])));
         nx = fmaxf(nx, fabsf((float)xto[f]));
-#pragma unroll
-        for (int b = 0; b < 6; ++b) xblk[f][b] = alpha * xtb[b] + (1 - alpha) * xblk[f][b];
         xo[f] = alpha * xto[f] + (1 - alpha) * xo[f];
+        sm.xs[j][f][c] = xo[f];
       }
     }
     ++it;
+    __syncthreads();
     // --- stopping test (workgroup-uniform)
     if (it % P.check_every == 0 || it == P.max_iter) {
       float v4[4] = {rp, rs, nz, nx};
@@ -933,6 +938,11 @@ solve_kernel(const DevParams P, const int B,
     // wrench of the final x, then X_i = s_i + Gam_t b
     __syncthreads();
     if (valid) {
+      RT xblk[2][6];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) xblk[f][b] = sm.xs[j][f][b];
       RT val;
       if (c < 3) {
         RT t0[3], t1[3];
