@@ -47,7 +47,7 @@ class Params:
         self.tau_max = np.asarray(biped.tau_max, float).reshape(3)
         self.tau_min = np.asarray(biped.tau_min, float).reshape(3)
         # solver
-        self.rho = 0.1
+        self.rho = 0.03
         self.rho_eq_scale = 1e3
         self.rho_lo = 3e-4
         self.rho_hi_f = 1.0
