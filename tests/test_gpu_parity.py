@@ -114,3 +114,37 @@ def test_full_size_properties():
                             x_cmd=s["x_cmd"][100:164])
     assert np.array_equal(controls[100:164], c3)
     print("iters mean %.1f max %d, nfactor mean %.2f" % (info["iters"].mean(), info["iters"].max(), info["nfactor"].mean()))
+
+
+@pytest.mark.parametrize("name,B,h,gait,seed,kw", [
+    ("cfg3", 4096, 16, "walking", 2, dict(vx_cmd=True)),
+    ("cfg4", 65536, 10, "mixed", 3, dict(vx_cmd=True)),
+    ("cfg5_eighth", 8192, 20, "walking", 4, dict(vx_cmd=True, per_step_mu=True)),
+])
+def test_baseline_config_shapes_at_scale(name, B, h, gait, seed, kw):
+    """BASELINE configs 3-5 at (or, for config 5, at one rank's share of) their full sizes: every
+    instance converges and every constraint of REF:220-271 holds (size-independent properties)."""
+    s = util.synth_batch(B, h, seed, gait=gait, **kw)
+    solver, mpc = _solver(h, s["half"])
+    solver.close()
+    import biped_mpc_py_amd as bm
+    solver = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    states, controls, info = solver.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])
+    assert (info["status"] == 0).all(), np.bincount(info["status"])
+    assert not np.isnan(controls).any() and not np.isnan(states).any()
+    mu = s["mu"] if s["mu"] is not None else np.full((B, h, 2), 0.5)
+    f = controls.reshape(B, h, 4, 3)
+    tol = 2e-3
+    for j in range(2):
+        c = s["contact"][:, :, j].astype(float)
+        fx, fy, fz = f[:, :, j, 0], f[:, :, j, 1], f[:, :, j, 2]
+        assert (fz >= -tol).all() and (fz <= 500 * c + tol).all()                      # REF:240-249
+        assert (np.abs(fx) <= mu[:, :, j] * fz + tol).all() and (np.abs(fy) <= mu[:, :, j] * fz + tol).all()
+        assert (np.abs(f[:, :, 2 + j, 0]) <= tol).all()                                 # tau_max[0] = 0
+        assert (np.abs(f[:, :, 2 + j, 1]) <= 67 * c + tol).all() and (np.abs(f[:, :, 2 + j, 2]) <= 33.5 * c + tol).all()
+    # dynamics consistency: v_z after step 1 from the first control row (REF:165-184, forward Euler)
+    vz1 = s["x_fb"][:, 11].astype(np.float32) - 9.81 * 0.04 + 0.04 / 12 * (f[:, 0, 0, 2] + f[:, 0, 1, 2])
+    assert np.abs(states[:, 0, 11] - vz1).max() <= 1e-4
+    print(name, "iters mean %.1f max %d  nfactor mean %.2f max %d" %
+          (info["iters"].mean(), info["iters"].max(), info["nfactor"].mean(), info["nfactor"].max()))
+    solver.close()
