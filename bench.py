@@ -180,6 +180,14 @@ def main():
     if rank == 0:
         fl, parts = flops_per_solve(H, float(iters.mean()), float(nfac.mean()))
         achieved = fl * B / (kernel_ms * 1e-3) / 1e12
+        traffic = None                     # HBM bytes per launch from the committed PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
+                pm = json.load(fh)
+            if pm.get("batch") == B:
+                traffic = pm["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "MPC QP solves/sec (N=10, 2-contact)",
             "value": world * B * args.steps / elapsed,
@@ -195,7 +203,7 @@ def main():
                        "mean_factorisations": float(nfac.mean()),
                        "not_converged": int((status != 0).sum())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "bmpc::solve_kernel<10,double>", "kernel_ms": kernel_ms,
                          "flops_per_solve": fl, "flops_parts": parts,
                          "hbm_algorithmic_bytes_per_solve": 4 * (12 + 6 + 1) + 2 * H + 4 * 25 * H + 20},
