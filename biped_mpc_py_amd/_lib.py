@@ -46,6 +46,26 @@ class CParams(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7; if libbmpc.so pulled in
+    /opt/rocm's copy first and torch then loaded its own, the second runtime finds no device ("No HIP GPUs
+    are available").  So when torch is installed, its copy is loaded (globally) before libbmpc.so, whose
+    DT_NEEDED libamdhip64.so.7 then resolves to it -- whether or not the caller ever imports torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libbmpc.so once and declare prototypes.  Raises if it has not been built."""
     global _lib
@@ -55,6 +75,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  biped_mpc_py_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     lib.bmpc_abi_version.restype = ip

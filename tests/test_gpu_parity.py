@@ -148,3 +148,17 @@ def test_baseline_config_shapes_at_scale(name, B, h, gait, seed, kw):
     print(name, "iters mean %.1f max %d  nfactor mean %.2f max %d" %
           (info["iters"].mean(), info["iters"].max(), info["nfactor"].mean(), info["nfactor"].max()))
     solver.close()
+
+
+def test_library_and_torch_share_one_hip_runtime():
+    """libbmpc.so loaded BEFORE torch (the order build() -> smoke() produces) must not leave the process with
+    two HIP runtimes (symptom: 'No HIP GPUs are available' / BMPC_ERR_NO_DEVICE).  Run in a child process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from biped_mpc_py_amd import _lib; _lib.load()\n"
+            "import torch; assert torch.cuda.is_available()\n"
+            "import biped_mpc_py_amd as bm; s = bm.BatchSolver(max_batch=8)\n"
+            "x = torch.zeros(4, device='cuda'); print('ok', float(x.sum()))\n") % util.ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

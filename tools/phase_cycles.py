@@ -1,5 +1,5 @@
 import sys, numpy as np, torch, ctypes as C
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import biped_mpc_py_amd as bm
 from biped_mpc_py_amd import _lib
 from bench import synth

@@ -2,7 +2,7 @@
 constraint feasibility for the BASELINE config shapes (no oracle: too slow at these sizes)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import biped_mpc_py_amd as bm
 from tests import util
 
