@@ -6,8 +6,8 @@ does not load the shared library; the first solver call does, and raises if it i
 """
 from .params import MPC, Biped, pack_params                                  # noqa: F401
 from .api import (BatchSolver, solve_mpc, solve_mpc_batch, get_contact_sequence,   # noqa: F401
-                  phase_index)
+                  phase_index, lowLevelControl, getFootPositionWorld)
 from . import sharding                                                        # noqa: F401
 
 __all__ = ["MPC", "Biped", "pack_params", "BatchSolver", "solve_mpc", "solve_mpc_batch",
-           "get_contact_sequence", "phase_index", "sharding"]
+           "get_contact_sequence", "phase_index", "lowLevelControl", "getFootPositionWorld", "sharding"]

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -16,6 +16,8 @@ EXPORTS = (
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
     "bmpc_solve_batch", "bmpc_solve_batch_device", "bmpc_synchronize",
     "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
+    "bmpc_foot_position_world", "bmpc_foot_position_world_device",
+    "bmpc_low_level_control", "bmpc_low_level_control_device",
 )
 
 
@@ -40,6 +42,7 @@ class CParams(C.Structure):
         ("eps_pri", C.c_double), ("eps_dua", C.c_double),
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
         ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("reserved", C.c_int32),
+        ("kp", C.c_double * 9), ("kd", C.c_double * 9), ("swingHeight", C.c_double), ("hip_offset", C.c_double * 3),
     ]
 
 
@@ -92,6 +95,10 @@ def load():
     lib.bmpc_synchronize.argtypes = [vp]
     lib.bmpc_debug_assemble.argtypes = [vp, ip] + [vp] * 10
     lib.bmpc_debug_set_profile.argtypes = [vp, vp]
+    lib.bmpc_foot_position_world.argtypes = [vp, ip, vp, vp, vp]
+    lib.bmpc_foot_position_world_device.argtypes = [vp, ip, vp, vp, vp, vp]
+    lib.bmpc_low_level_control.argtypes = [vp, ip] + [vp] * 8
+    lib.bmpc_low_level_control_device.argtypes = [vp, ip] + [vp] * 9
     lib.bmpc_last_kernel_ms.argtypes = [vp, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -146,6 +146,35 @@ class BatchSolver:
             chk(status, torch.int32, (B,)) or None, chk(nfactor, torch.int32, (B,)) or None, st))
         return controls, states
 
+    # ---- the step either side of the solve ------------------------------------
+    def foot_position_world(self, x_fb, q):
+        """Batched REF:406-424 `getFootPositionWorld`: x_fb (B,12), q (B,10) -> pf_w (B,6) fp64."""
+        x_fb = np.ascontiguousarray(np.asarray(x_fb, np.float32).reshape(-1, 12))
+        B = x_fb.shape[0]
+        q = np.ascontiguousarray(np.asarray(q, np.float32).reshape(B, 10))
+        pf = np.empty((B, 6), np.float32)
+        _lib.check(self._lib.bmpc_foot_position_world(self._h, B, _ptr(x_fb), _ptr(q), _ptr(pf)))
+        return pf.astype(np.float64)
+
+    def low_level_control(self, x_fb, t, pf_w, q, qd, contact0, u0):
+        """Batched REF:444-470 `lowLevelControl`: contact0 (B,2) = contact[0, 0:2], u0 (B,12) = controls[0]
+        -> tau (B,10) fp64."""
+        x_fb = np.ascontiguousarray(np.asarray(x_fb, np.float32).reshape(-1, 12))
+        B = x_fb.shape[0]
+        t = np.ascontiguousarray(np.asarray(t, np.float64).reshape(B))
+        pf_w = np.ascontiguousarray(np.asarray(pf_w, np.float32).reshape(B, 6))
+        q = np.ascontiguousarray(np.asarray(q, np.float32).reshape(B, 10))
+        qd = np.ascontiguousarray(np.asarray(qd, np.float32).reshape(B, 10))
+        c0 = np.asarray(contact0).reshape(B, 2)
+        if not np.isin(c0, (0, 1)).all():
+            raise ValueError("contact entries must be 0 or 1")
+        c0 = np.ascontiguousarray(c0.astype(np.uint8))
+        u0 = np.ascontiguousarray(np.asarray(u0, np.float32).reshape(B, 12))
+        tau = np.empty((B, 10), np.float32)
+        _lib.check(self._lib.bmpc_low_level_control(self._h, B, _ptr(x_fb), _ptr(t), _ptr(pf_w), _ptr(q), _ptr(qd),
+                                                    _ptr(c0), _ptr(u0), _ptr(tau)))
+        return tau.astype(np.float64)
+
     def last_kernel_ms(self):
         ms = C.c_float(-1.0)
         _lib.check(self._lib.bmpc_last_kernel_ms(self._h, C.byref(ms)))
@@ -197,3 +226,20 @@ def solve_mpc(x_fb, t, foot, mpc, biped, contact, half=None, device=0, solver_op
     states, controls = solve_mpc_batch(x_fb[None], [t], foot[None], contact[None, :h, :], mpc=mpc, biped=biped,
                                        half=half, device=device, solver_options=solver_options)
     return states[0], controls[0]
+
+
+def getFootPositionWorld(x_fb, q, biped, mpc=None, device=0):
+    """Drop-in for REF:406-424: returns pf_w (6,1) fp64 like the reference."""
+    from .params import MPC
+    solver = _cached_solver(mpc if mpc is not None else MPC(), biped, None, device, None)
+    return solver.foot_position_world(np.asarray(x_fb, float).reshape(1, 12), np.asarray(q, float).reshape(1, 10)).reshape(6, 1)
+
+
+def lowLevelControl(x_fb, t, pf_w, q, qd, mpc, biped, contact, u, device=0):
+    """Drop-in for REF:444-470: same arguments (u is the (12,1) column REF:493 builds), returns tau (10,1) fp64."""
+    solver = _cached_solver(mpc, biped, None, device, None)
+    contact = np.asarray(contact)
+    tau = solver.low_level_control(np.asarray(x_fb, float).reshape(1, 12), [float(t)], np.asarray(pf_w, float).reshape(1, 6),
+                                   np.asarray(q, float).reshape(1, 10), np.asarray(qd, float).reshape(1, 10),
+                                   contact[0, 0:2].reshape(1, 2), np.asarray(u, float).reshape(1, 12))
+    return tau.reshape(10, 1)

@@ -2,6 +2,7 @@
 // There is deliberately no CPU path here: without a HIP device every entry point that would
 // compute returns BMPC_ERR_NO_DEVICE.
 #include "bmpc_kernels.hip"
+#include "bmpc_lowlevel.hip"
 
 #include <cmath>
 #include <cstdarg>
@@ -103,6 +104,9 @@ struct bmpc_handle_s {
   DevBuf<uint8_t> contact;
   DevBuf<int32_t> phase, iters, status, nfactor;
   DevBuf<double> dbg;
+  DevBuf<float> ll_q, ll_qd, ll_pf, ll_u0, ll_tau;
+  DevBuf<double> ll_t;
+  DevBuf<uint8_t> ll_c0;
   long long* prof_dev = nullptr;   // optional cycle-stamp buffer (bmpc_debug_set_profile)
 };
 
@@ -171,6 +175,10 @@ int bmpc_default_params(bmpc_params* p, int h) {
   p->rho = 0.03; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 10.0;
   p->alpha = 1.6; p->eps_pri = 1e-7; p->eps_dua = 1e-7;
   p->max_iter = 400; p->check_every = 5; p->adapt_start = 20; p->adapt_every = 10; p->max_refactor = 40;
+  p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
+  p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31
+  p->swingHeight = 0.1;                                               // REF:32
+  p->hip_offset[0] = -0.005; p->hip_offset[1] = 0.047; p->hip_offset[2] = -0.126;   // REF:43
   return BMPC_OK;
 }
 
@@ -207,6 +215,8 @@ int bmpc_destroy(bmpc_handle h) {
   h->x_fb.release(); h->foot.release(); h->x_cmd.release(); h->mu.release(); h->controls.release();
   h->states.release(); h->resid.release(); h->contact.release(); h->phase.release(); h->iters.release();
   h->status.release(); h->nfactor.release(); h->dbg.release();
+  h->ll_q.release(); h->ll_qd.release(); h->ll_pf.release(); h->ll_u0.release(); h->ll_tau.release();
+  h->ll_t.release(); h->ll_c0.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -320,6 +330,87 @@ int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* fo
   if (foot_ref) HIP_TRY(hipMemcpyAsync(foot_ref, h->dbg.p + o_fr, n * H * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
   if (Gt) HIP_TRY(hipMemcpyAsync(Gt, h->dbg.p + o_gt, n * NW * NW * sizeof(double), hipMemcpyDeviceToHost, st));
   if (qt) HIP_TRY(hipMemcpyAsync(qt, h->dbg.p + o_qt, n * NW * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
+static bmpc::LowLevelParams ll_params(const bmpc_params& p) {
+  bmpc::LowLevelParams q;
+  q.h = p.h; q.dt = p.dt; q.kv = p.kv; q.swing_height = p.swingHeight;
+  for (int i = 0; i < 12; ++i) q.x_cmd[i] = p.x_cmd[i];
+  for (int i = 0; i < 9; ++i) { q.kp[i] = p.kp[i]; q.kd[i] = p.kd[i]; }
+  for (int i = 0; i < 3; ++i) q.hip_offset[i] = p.hip_offset[i];
+  return q;
+}
+
+int bmpc_foot_position_world_device(bmpc_handle h, int B, const float* x_fb, const float* q, float* pf_w, void* stream) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B == 0) return BMPC_OK;
+  if (!x_fb || !q || !pf_w) return fail(BMPC_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipLaunchKernelGGL(bmpc::foot_world_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ll_params(h->params), B, x_fb, q, pf_w);
+  HIP_TRY(hipGetLastError());
+  return BMPC_OK;
+}
+
+int bmpc_foot_position_world(bmpc_handle h, int B, const float* x_fb, const float* q, float* pf_w) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B == 0) return BMPC_OK;
+  if (!x_fb || !q || !pf_w) return fail(BMPC_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B;
+  HIP_TRY(h->x_fb.ensure(n * 12)); HIP_TRY(h->ll_q.ensure(n * 10)); HIP_TRY(h->ll_pf.ensure(n * 6));
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->x_fb.p, x_fb, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_q.p, q, n * 10 * sizeof(float), hipMemcpyHostToDevice, st));
+  int rc = bmpc_foot_position_world_device(h, B, h->x_fb.p, h->ll_q.p, h->ll_pf.p, st);
+  if (rc != BMPC_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(pf_w, h->ll_pf.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
+int bmpc_low_level_control_device(bmpc_handle h, int B, const float* x_fb, const double* t, const float* pf_w,
+                                  const float* q, const float* qd, const uint8_t* contact0, const float* u0,
+                                  float* tau, void* stream) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B == 0) return BMPC_OK;
+  if (!x_fb || !t || !pf_w || !q || !qd || !contact0 || !u0 || !tau) return fail(BMPC_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipLaunchKernelGGL(bmpc::lowlevel_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ll_params(h->params), B, x_fb, t,
+                     pf_w, q, qd, contact0, u0, tau);
+  HIP_TRY(hipGetLastError());
+  return BMPC_OK;
+}
+
+int bmpc_low_level_control(bmpc_handle h, int B, const float* x_fb, const double* t, const float* pf_w,
+                           const float* q, const float* qd, const uint8_t* contact0, const float* u0, float* tau) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B == 0) return BMPC_OK;
+  if (!x_fb || !t || !pf_w || !q || !qd || !contact0 || !u0 || !tau) return fail(BMPC_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B;
+  HIP_TRY(h->x_fb.ensure(n * 12)); HIP_TRY(h->ll_t.ensure(n)); HIP_TRY(h->ll_pf.ensure(n * 6));
+  HIP_TRY(h->ll_q.ensure(n * 10)); HIP_TRY(h->ll_qd.ensure(n * 10)); HIP_TRY(h->ll_c0.ensure(n * 2));
+  HIP_TRY(h->ll_u0.ensure(n * 12)); HIP_TRY(h->ll_tau.ensure(n * 10));
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->x_fb.p, x_fb, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_t.p, t, n * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_pf.p, pf_w, n * 6 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_q.p, q, n * 10 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_qd.p, qd, n * 10 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_c0.p, contact0, n * 2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->ll_u0.p, u0, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  int rc = bmpc_low_level_control_device(h, B, h->x_fb.p, h->ll_t.p, h->ll_pf.p, h->ll_q.p, h->ll_qd.p, h->ll_c0.p,
+                                         h->ll_u0.p, h->ll_tau.p, st);
+  if (rc != BMPC_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(tau, h->ll_tau.p, n * 10 * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return BMPC_OK;
 }

@@ -81,6 +81,18 @@ def pack_params(mpc=None, biped=None, half=None, solver_options=None):
         arr = getattr(cp, name)
         for i in range(3):
             arr[i] = v[i]
+    for name in ("kp", "kd"):                                   # REF:30-31 (optional on foreign objects)
+        if hasattr(mpc, name):
+            v = np.asarray(getattr(mpc, name), float).reshape(9)
+            arr = getattr(cp, name)
+            for i in range(9):
+                arr[i] = v[i]
+    if hasattr(mpc, "swingHeight"):
+        cp.swingHeight = float(mpc.swingHeight)
+    if hasattr(biped, "hip_offset"):
+        v = np.asarray(biped.hip_offset, float).reshape(3)
+        for i in range(3):
+            cp.hip_offset[i] = v[i]
     for k, v in (solver_options or {}).items():
         if k not in SOLVER_FIELDS:
             raise KeyError(f"unknown solver option {k!r}")

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 1
+#define BMPC_ABI_VERSION 2
 
 enum bmpc_status {
   BMPC_OK = 0,
@@ -76,6 +76,10 @@ typedef struct bmpc_params {
   int32_t adapt_every;       /* re-classification period (0 = never) */
   int32_t max_refactor;      /* cap on re-factorisations per instance */
   int32_t reserved;
+  /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
+  double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
+  double swingHeight;        /* REF:32 */
+  double hip_offset[3];      /* REF:43 */
 } bmpc_params;
 
 typedef struct bmpc_handle_s* bmpc_handle;
@@ -143,6 +147,24 @@ int bmpc_debug_assemble(bmpc_handle h, int B,
                         const float* x_fb, const float* foot, const uint8_t* contact,
                         const int32_t* phase, const float* x_cmd, const float* mu,
                         double* x_ref, double* foot_ref, double* Gt, double* qt);
+
+/*
+ * The step either side of the MPC solve, batched; HOST pointers, synchronous.
+ *   bmpc_foot_position_world  replaces getFootPositionWorld (REF:406-424, with getFootPositionBody REF:367-404):
+ *       x_fb [B][12], q [B][10] joint angles  ->  pf_w [B][6]
+ *   bmpc_low_level_control    replaces lowLevelControl (REF:444-470, with getLegKinematics REF:306-365 and
+ *       swingLegControl REF:426-442):
+ *       x_fb [B][12], t [B] (seconds, fp64), pf_w [B][6], q [B][10], qd [B][10],
+ *       contact0 [B][2] = contact[0, 0:2], u0 [B][12] = controls[0]  ->  tau [B][10]
+ * The *_device variants take DEVICE pointers and a stream (NULL = the handle's) and do not synchronise.
+ */
+int bmpc_foot_position_world(bmpc_handle h, int B, const float* x_fb, const float* q, float* pf_w);
+int bmpc_foot_position_world_device(bmpc_handle h, int B, const float* x_fb, const float* q, float* pf_w, void* stream);
+int bmpc_low_level_control(bmpc_handle h, int B, const float* x_fb, const double* t, const float* pf_w,
+                           const float* q, const float* qd, const uint8_t* contact0, const float* u0, float* tau);
+int bmpc_low_level_control_device(bmpc_handle h, int B, const float* x_fb, const double* t, const float* pf_w,
+                                  const float* q, const float* qd, const uint8_t* contact0, const float* u0,
+                                  float* tau, void* stream);
 
 /* Diagnostics: when device_buf (DEVICE pointer, [max_batch][8] int64) is non-NULL every later solve
  * writes per-instance shader-clock stamps {setup, block algebra, dense sweeps, total, iters,

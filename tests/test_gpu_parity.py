@@ -162,3 +162,42 @@ def test_library_and_torch_share_one_hip_runtime():
             "x = torch.zeros(4, device='cuda'); print('ok', float(x.sum()))\n") % util.ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_low_level_control_and_fk_on_device():
+    """batched FK and force->torque map against the reference-pinned fixtures
+    (unit_functions.npz: FK from the reference; known_*.npz: tau from the reference's lowLevelControl)
+    and against the oracle restatement on random joint states.  Tolerance 2e-5 (fp32 I/O)."""
+    import biped_mpc_py_amd as bm
+    from oracle import bmpc_oracle as orc
+    d = util.load("unit_functions")
+    solver = bm.BatchSolver(max_batch=256)
+    pf = solver.foot_position_world(d["xs"], d["qj"])
+    assert np.abs(pf - d["fk"]).max() <= 2e-6
+    for name in ("known_standing", "known_walking_t0"):
+        k = util.load(name)
+        mpc, biped = bm.MPC(), bm.Biped()
+        pfw = bm.getFootPositionWorld(k["x_fb"], k["q_joint"], biped)
+        assert pfw.shape == (6, 1) and np.abs(pfw - k["pf_w"]).max() <= 2e-6
+        u0 = k["controls"][0, :].reshape(-1, 1)                         # REF:493
+        tau = bm.lowLevelControl(k["x_fb"], float(k["t"]), k["pf_w"], k["q_joint"], k["qd_joint"], mpc, biped,
+                                 k["contact"], u0)
+        assert tau.shape == (10, 1)
+        assert np.abs(tau - k["tau"]).max() <= 2e-5 * max(1.0, np.abs(k["tau"]).max())
+    # random joint states, swing and stance legs, non-zero joint velocities and time
+    rng = np.random.default_rng(7)
+    B = 128
+    xs = np.stack([util.synth_batch(1, 10, 100 + i)["x_fb"][0] for i in range(B)])
+    q = rng.uniform(-1, 1, (B, 10)); qd = rng.uniform(-2, 2, (B, 10)); t = rng.uniform(0, 2, B)
+    u0 = rng.uniform(-50, 150, (B, 12)); c0 = rng.integers(0, 2, (B, 2))
+    pf = solver.foot_position_world(xs, q)
+    tau = solver.low_level_control(xs, t, pf, q, qd, c0, u0)
+    m, b = orc.MPC(), orc.Biped()
+    for i in range(B):
+        x32 = xs[i].astype(np.float32).astype(float)
+        ref_pf = orc.getFootPositionWorld(x32, q[i].astype(np.float32).astype(float), b)
+        assert np.abs(pf[i] - ref_pf.reshape(-1)).max() <= 2e-6
+        ref = orc.lowLevelControl(x32, float(t[i]), pf[i].astype(np.float32).astype(float).reshape(6, 1),
+                                  q[i].astype(np.float32).astype(float), qd[i].astype(np.float32).astype(float), m, b,
+                                  np.tile(c0[i], (10, 1)), u0[i].astype(np.float32).astype(float).reshape(12, 1))
+        assert np.abs(tau[i] - ref.reshape(-1)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
