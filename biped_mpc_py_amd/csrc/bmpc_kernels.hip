@@ -846,6 +846,7 @@ solve_kernel(const DevParams P, const int B,
     __syncthreads();
     // --- E7: z~ = A x~, relaxation, projection, dual update
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
+    int nanl = 0;                              // fmaxf drops NaNs: track them explicitly
     if (valid) {
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
@@ -876,6 +877,7 @@ solve_kernel(const DevParams P, const int B,
           rp = fmaxf(rp, fabsf((float)(ztg - zn)));
           nz = fmaxf(nz, fabsf((float)ztg));
         }
+        nanl |= !(xto[f] == xto[f]);
         rs = fmaxf(rs, fabsf((float)(xto[f] - xo[f])));
         nx = fmaxf(nx, fabsf((float)xto[f]));
         xo[f] = alpha * xto[f] + (1 - alpha) * xo[f];
@@ -890,7 +892,7 @@ solve_kernel(const DevParams P, const int B,
       block_max4<NT>(v4, sm.red);
       res_p = v4[0];
       res_s = v4[1];
-      const bool bad = !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
+      const bool bad = __syncthreads_or(nanl) || !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
       if (bad) { status = 2; break; }
       if (v4[0] <= P.eps_pri * fmaxf(1.f, v4[2]) && v4[1] <= P.eps_dua * fmaxf(1.f, v4[3])) { status = 0; break; }
     }

@@ -86,3 +86,23 @@ def test_argument_validation(lib):
     assert lib.bmpc_destroy(None) == 0
     assert lib.bmpc_synchronize(None) == -1
     assert lib.bmpc_set_params(None, C.byref(cp)) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No shared library -> ImportError with build instructions; nothing falls back to the CPU."""
+    from biped_mpc_py_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libbmpc.so"))
+    with pytest.raises(ImportError) as ei:
+        _lib.load()
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: no module of the package may import it."""
+    pkg = os.path.join(util.ROOT, "biped_mpc_py_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f

@@ -201,3 +201,36 @@ def test_low_level_control_and_fk_on_device():
                                   q[i].astype(np.float32).astype(float), qd[i].astype(np.float32).astype(float), m, b,
                                   np.tile(c0[i], (10, 1)), u0[i].astype(np.float32).astype(float).reshape(12, 1))
         assert np.abs(tau[i] - ref.reshape(-1)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_edge_inputs_and_parameter_changes():
+    """Empty batch, batch of one, NaN input (reported per instance, batch not failed), parameter update
+    through bmpc_set_params semantics (a new solver with different mu / x_cmd changes the answer consistently)."""
+    import biped_mpc_py_amd as bm
+    from oracle import bmpc_oracle as orc
+    d = util.load("cfg2_standing_h10")
+    solver = bm.BatchSolver(max_batch=16)
+    st, ct, info = solver.solve(np.zeros((0, 12)), np.zeros((0, 6)), np.zeros((0, 10, 2), np.uint8), np.zeros(0, np.int32))
+    assert ct.shape == (0, 10, 12) and st.shape == (0, 10, 13)
+    x = d["x_fb"][:4].copy()
+    x[2, 5] = np.nan
+    st, ct, info = solver.solve(x, d["foot"][:4], d["contact"][:4], np.zeros(4, np.int32))
+    assert info["status"][2] == 2 and (info["status"][[0, 1, 3]] == 0).all()
+    assert util.rel_err(ct[[0, 1, 3]], d["controls"][[0, 1, 3]]).max() <= util.REL_TOL
+    with pytest.raises(ValueError):
+        solver.solve(d["x_fb"][:2], d["foot"][:2], np.full((2, 10, 2), 2), np.zeros(2, np.int32))
+    from biped_mpc_py_amd._lib import BmpcError
+    with pytest.raises(BmpcError):
+        solver.solve(d["x_fb"][:32], d["foot"][:32], d["contact"][:32], np.zeros(32, np.int32))   # > max_batch
+    # different friction and command -> the oracle with the same parameters agrees
+    mpc, biped = bm.MPC(), bm.Biped()
+    biped.mu = 0.3
+    mpc.x_cmd = np.array([0, 0, 0, 0.05, 0, 0.52, 0, 0, 0, 0.2, 0, 0], float)
+    s2 = bm.BatchSolver(mpc=mpc, biped=biped, max_batch=4)
+    _, c2, i2 = s2.solve(d["x_fb"][:2], d["foot"][:2], d["contact"][:2], np.zeros(2, np.int32))
+    om, ob = orc.MPC(), orc.Biped()
+    ob.mu, om.x_cmd = 0.3, mpc.x_cmd
+    for i in range(2):
+        _, ref = orc.solve_mpc(d["x_fb"][i].astype(np.float32).astype(float), 0.0, d["foot"][i].astype(np.float32).astype(float),
+                               om, ob, d["contact"][i])
+        assert util.rel_err(c2[i][None], ref[None]).max() <= util.REL_TOL
