@@ -26,6 +26,8 @@
 
 namespace bmpc {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct DevParams {
   int h, half, max_iter, check_every, adapt_start, adapt_every, max_refactor, pad0;
   double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
@@ -50,40 +52,53 @@ struct Dims {
   static constexpr int NPAIR = H * (H - 1) / 2;          // (i > j) step pairs
 };
 
-// LDS image of one instance.
+// LDS image of one instance.  The factor scratch (f64 6x6 blocks) and the per-iteration exchange
+// vectors (+ the set-up-only step data) are never live at the same time and share one region, which
+// brings h = 10 under 20 KB: eight workgroups per CU.
 template <int H, typename RT>
-struct alignas(16) Smem {
+struct FacScratch {
+  double M0[H][6][6];        // D0 -> D0^-1 -> F
+  double M1[H][6][6];        // D1 -> D1^-1 -> Ka^-1
+  double ex[H][3][6];        // pivot-column exchange for the cooperative 6x6 sweeps
+};
+template <int H, typename RT>
+struct IterScratch {
   static constexpr int NW = Dims<H>::NW;
-  // iteration vectors
   RT xt[H][2][6];            // x tilde
-  RT xs[H][2][6];            // x (relaxed iterate); re-read per iteration instead of living in VGPRs
   RT wg[H][2][6];            // y + rho (A x - z) on the general rows
   RT bw[NW];                 // net wrench of x
   RT gb[NW];                 // wrench-space gradient Gt b + qt
   alignas(16) float r32[H][2][6];   // KKT residual, control space
   alignas(16) float beta[NW];
   alignas(16) float gam[NW];
+  // set-up only
+  RT Rv[H][9];               // R_inv (REF:160-164)
+  RT Pre[H][9];              // prefix sums of R_inv
+  RT err[H][12];             // free response - reference
+};
+template <int H, typename RT>
+struct alignas(16) Smem {
+  static constexpr int NW = Dims<H>::NW;
+  union alignas(16) {
+    FacScratch<H, RT> fac;
+    IterScratch<H, RT> itv;
+  } u;
+  RT xs[H][2][6];            // x (relaxed iterate); re-read per iteration instead of living in VGPRs
   alignas(16) float piv[2][NW];     // sweep pivot column, double buffered
   // block-diagonal part of K^-1
   alignas(16) float L[H][2][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
-  alignas(16) float Na[H][2][6][12];    // N Ka^-1 N'            [foot][var][foot*6 + var]
-  // step data (setup)
+  alignas(16) float Kn[H][2][6][6];     // [0]: Ka^-1, [1]: T Ka^-1   (N Ka^-1 N' applied as N (Ka^-1 (N' r)))
+  // step data
   RT Iw[H][9];               // world inverse inertia
-  RT Rv[H][9];               // R_inv (REF:160-164)
-  RT Pre[H][9];              // prefix sums of R_inv
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
-  RT err[H][12];             // free response - reference
-  RT xref[H][12];            // x_ref[:, j]
-  RT fref[H][6];             // foot_ref[:, j]
+  RT s0[H][12];              // free response (X with u = 0)
   float Me[Dims<H>::NPAIR > 0 ? Dims<H>::NPAIR : 1][9];   // dt^2 (P_i - P_j) Iw_j, i > j (data: f32)
-  // factor scratch
   float rvg[H][2][6];
-  double M0[H][6][6];        // D0 -> D0^-1 -> F
-  double M1[H][6][6];        // D1 -> D1^-1
-  double M2[H][6][6];        // Ka^-1
-  double ex[H][3][6];        // pivot-column exchange for the cooperative 6x6 sweeps
+  float muf[H][2];           // friction coefficient per step and foot
+  RT Gu[6][6];               // mu-free part of the general rows of a foot block, and its transpose
+  RT GuT[6][6];
+  float eyz[6];              // body y and z axes in the world frame (columns 1, 2 of eul2rotm(x_fb))
   float red[4][Dims<H>::NT / 64];
-  int flag[2];
 };
 
 __device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
@@ -122,7 +137,7 @@ __device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool
   for (int k = 0; k < 6; ++k) {
     if (valid) {
 #pragma unroll
-      for (int q = 0; q < NM; ++q) sm.ex[j][q][c] = m[q][k];
+      for (int q = 0; q < NM; ++q) sm.u.fac.ex[j][q][c] = m[q][k];
     }
     __syncthreads();
     if (valid) {
@@ -130,7 +145,7 @@ __device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool
       for (int q = 0; q < NM; ++q) {
         double col[6];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) col[b] = sm.ex[j][q][b];
+        for (int b = 0; b < 6; ++b) col[b] = sm.u.fac.ex[j][q][b];
         const double pinv = 1.0 / col[k];
         const bool isp = (c == k);
         const double t = isp ? -pinv : m[q][k] * pinv;
@@ -209,11 +224,9 @@ solve_kernel(const DevParams P, const int B,
   const RT dt = (RT)P.dt;
   // 0/1 masks of this lane's component: runtime picks are done arithmetically (select chains over
   // register arrays get demoted to scratch by the compiler)
-  float mkf[6];
-  double mkd[6];
+  // (the factor-only masks are rebuilt inside factor() so that they do not occupy registers during
+  // the iterations)
   RT mk3[3];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { mkf[k] = (c == k) ? 1.f : 0.f; mkd[k] = (c == k) ? 1.0 : 0.0; }
 #pragma unroll
   for (int k = 0; k < 3; ++k) mk3[k] = (c % 3 == k) ? (RT)1 : (RT)0;
 
@@ -247,11 +260,15 @@ solve_kernel(const DevParams P, const int B,
       fr[0] = fx; fr[1] = fy; fr[2] = 0; fr[3] = fx; fr[4] = fy; fr[5] = 0;
     }
   }
-  if (valid && c == 0) {
+  if (valid && c == 0) {                       // debug views of the references (tests)
+    if (dbg.x_ref) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) sm.xref[j][i] = xr[i];
+      for (int i = 0; i < 12; ++i) dbg.x_ref[((size_t)inst * H + j) * 12 + i] = (double)xr[i];
+    }
+    if (dbg.foot_ref) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) sm.fref[j][i] = fr[i];
+      for (int i = 0; i < 6; ++i) dbg.foot_ref[((size_t)inst * H + j) * 6 + i] = (double)fr[i];
+    }
   }
 
   RT Pj[9];                                    // prefix sum of R_inv up to this lane's step
@@ -279,7 +296,7 @@ solve_kernel(const DevParams P, const int B,
     const RT Rv[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};             // REF:160-164 inverted
     if (valid && c == 0) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) { sm.Iw[j][q] = Iw[q]; sm.Rv[j][q] = Rv[q]; }
+      for (int q = 0; q < 9; ++q) { sm.Iw[j][q] = Iw[q]; sm.u.itv.Rv[j][q] = Rv[q]; }
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -292,11 +309,11 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll 1
   for (int s = 0; s <= j; ++s)
 #pragma unroll
-    for (int q = 0; q < 9; ++q) Pj[q] += sm.Rv[s][q];
+    for (int q = 0; q < 9; ++q) Pj[q] += sm.u.itv.Rv[s][q];
   if (valid) {
     if (c == 0) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) sm.Pre[j][q] = Pj[q];
+      for (int q = 0; q < 9; ++q) sm.u.itv.Pre[j][q] = Pj[q];
     }
     // free response s_j - x_ref[:, j]   (X_j is the state after step j)
     const RT j1 = (RT)(j + 1);
@@ -312,34 +329,24 @@ solve_kernel(const DevParams P, const int B,
     e12[11] -= (RT)P.g * dt * j1;
     if (c == 0) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) sm.err[j][i] = e12[i] - xr[i];
+      for (int i = 0; i < 12; ++i) { sm.u.itv.err[j][i] = e12[i] - xr[i]; sm.s0[j][i] = e12[i]; }
     }
   }
   __syncthreads();
-  if (valid) {
-    if (dbg.x_ref) {
-      dbg.x_ref[((size_t)inst * H + j) * 12 + c] = (double)sm.xref[j][c];
-      dbg.x_ref[((size_t)inst * H + j) * 12 + 6 + c] = (double)sm.xref[j][6 + c];
-    }
-    if (dbg.foot_ref) dbg.foot_ref[((size_t)inst * H + j) * 6 + c] = (double)sm.fref[j][c];
-  }
-  // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2
-  {
-    int idx = 0;
-#pragma unroll 1
-    for (int i = 1; i < H; ++i)
-#pragma unroll 1
-      for (int j2 = 0; j2 < i; ++j2, ++idx) {
-        if (idx % NT != l) continue;
+  // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2: one (i, j2) pair per lane and pass
+  for (int idx = l; idx < Dims<H>::NPAIR; idx += NT) {
+    int i = (int)((1.f + sqrtf(1.f + 8.f * (float)idx)) * 0.5f);     // invert idx = i (i - 1) / 2 + j2
+    i -= (i * (i - 1) / 2 > idx) ? 1 : 0;
+    i += ((i + 1) * i / 2 <= idx) ? 1 : 0;
+    const int j2 = idx - i * (i - 1) / 2;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            RT s = 0;
+      for (int b = 0; b < 3; ++b) {
+        RT s = 0;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) s += (sm.Pre[i][3 * a + q] - sm.Pre[j2][3 * a + q]) * sm.Iw[j2][3 * q + b];
-            sm.Me[idx][3 * a + b] = (float)(dt * dt * s);
-          }
+        for (int q = 0; q < 3; ++q) s += (sm.u.itv.Pre[i][3 * a + q] - sm.u.itv.Pre[j2][3 * a + q]) * sm.Iw[j2][3 * q + b];
+        sm.Me[idx][3 * a + b] = (float)(dt * dt * s);
       }
   }
   __syncthreads();
@@ -387,10 +394,10 @@ solve_kernel(const DevParams P, const int B,
         if (i > j) {
           const float* m1 = sm.Me[pair_index(i, j)];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) s += (RT)m1[3 * q + a] * (RT)P.Q[q] * sm.err[i][q];
+          for (int q = 0; q < 3; ++q) s += (RT)m1[3 * q + a] * (RT)P.Q[q] * sm.u.itv.err[i][q];
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) s += nw[q] * sm.err[i][6 + q];
+        for (int q = 0; q < 3; ++q) s += nw[q] * sm.u.itv.err[i][6 + q];
       }
       qt = 2 * s;
     } else {
@@ -409,7 +416,7 @@ solve_kernel(const DevParams P, const int B,
       RT s = 0;
 #pragma unroll 1
       for (int i = j; i < H; ++i)
-        s += kp * (RT)(i - j) * (RT)P.Q[3 + a] * sm.err[i][3 + a] + kvv * (RT)P.Q[9 + a] * sm.err[i][9 + a];
+        s += kp * (RT)(i - j) * (RT)P.Q[3 + a] * sm.u.itv.err[i][3 + a] + kvv * (RT)P.Q[9 + a] * sm.u.itv.err[i][9 + a];
       qt = 2 * s;
     }
     if (dbg.qt) dbg.qt[(size_t)inst * NW + l] = (double)qt;
@@ -418,67 +425,95 @@ solve_kernel(const DevParams P, const int B,
   if (dbg.prof) t_setup = clock64() - t_start;
 
   // ------------------------------------------------------------------ C. constraint data
-  float ey[3], ez[3];                         // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
-  {
-    RT sr, cr, sp, cp, sy, cy;
-    sincos_rt(xfb[0], &sr, &cr);
-    sincos_rt(xfb[1], &sp, &cp);
-    sincos_rt(xfb[2], &sy, &cy);
-    ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
-    ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
-  }
-  const float lh = (float)P.lh, lt = (float)P.lt;
-  float muf[2], lb[2], ub[2], R2v[2];
+  // General rows of a foot block: G = Gu - mu * [rows 0..3, column 2].  Gu (the mu-free part) is the same
+  // for every step and foot of the instance and lives in LDS (plus its transpose); a lane keeps only
+  // the two mu terms it needs.  Coefficients used with the f64 iterates are kept as RT so that no
+  // f32 copy + hoisted conversion doubles their register footprint.
+  RT lb[2], ub[2], R2v[2];
   bool eqb[2];
-  float grow[2][6], gcol[2][6];               // this lane's general row / its variable's column
-  float rf[2][3];                             // lever arms of this step
+  RT negmu[2], cmu[2];                        // -mu_f if this lane's general row is a friction row / if its variable is f_z
+  float drf[3];                               // r_0 - r_1 of this step
+  {
+    float ey[3], ez[3];                       // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
+    {
+      RT sr, cr, sp, cp, sy, cy;
+      sincos_rt(xfb[0], &sr, &cr);
+      sincos_rt(xfb[1], &sp, &cp);
+      sincos_rt(xfb[2], &sy, &cy);
+      ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
+      ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
+    }
+    if (l == 0) {
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const float cont = (float)contact[((size_t)inst * H + j) * 2 + f];
-    muf[f] = mu_in ? mu_in[((size_t)inst * H + j) * 2 + f] : (float)P.mu;
-    const int a = c < 3 ? c : c - 3;
-    ub[f] = cont * (float)(c < 3 ? P.f_max[a] : P.tau_max[a]);      // REF:240-249
-    lb[f] = cont * (float)(c < 3 ? P.f_min[a] : P.tau_min[a]);
-    eqb[f] = lb[f] == ub[f];
-    R2v[f] = (float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
-    float G[6][6];
-    general_rows(muf[f], ey, ez, lh, lt, G);
+      for (int a = 0; a < 3; ++a) { sm.eyz[a] = ey[a]; sm.eyz[3 + a] = ez[a]; }
+      float G[6][6];
+      general_rows(0.f, ey, ez, (float)P.lh, (float)P.lt, G);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      float gr = 0.f;
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int r = 0; r < 6; ++r) gr = fmaf(mkf[r], G[r][b], gr);   // row c
-      grow[f][b] = gr;
+        for (int b2 = 0; b2 < 6; ++b2) { sm.Gu[r][b2] = (RT)G[r][b2]; sm.GuT[b2][r] = (RT)G[r][b2]; }
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      float gc = 0.f;
-#pragma unroll
-      for (int b = 0; b < 6; ++b) gc = fmaf(mkf[b], G[r][b], gc);   // column c
-      gcol[f][r] = gc;
+    for (int f = 0; f < 2; ++f) {
+      const float cont = (float)contact[((size_t)inst * H + j) * 2 + f];
+      const float muf = mu_in ? mu_in[((size_t)inst * H + j) * 2 + f] : (float)P.mu;
+      if (valid && c == 0) sm.muf[j][f] = muf;
+      const int a = c < 3 ? c : c - 3;
+      const float ubf = cont * (float)(c < 3 ? P.f_max[a] : P.tau_max[a]);      // REF:240-249
+      const float lbf = cont * (float)(c < 3 ? P.f_min[a] : P.tau_min[a]);
+      ub[f] = (RT)ubf;
+      lb[f] = (RT)lbf;
+      eqb[f] = lbf == ubf;
+      R2v[f] = (RT)(float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
+      negmu[f] = c < 4 ? (RT)(-muf) : (RT)0;
+      cmu[f] = c == 2 ? (RT)(-muf) : (RT)0;
     }
 #pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2) rf[f][a2] = (float)sm.rr[j][f][a2];
+    for (int a2 = 0; a2 < 3; ++a2) drf[a2] = (float)sm.rr[j][0][a2] - (float)sm.rr[j][1][a2];
   }
 
   // ------------------------------------------------------------------ D. factor: L, Na, V for penalties rv
-  float rvb[2], rvg[2];                       // penalties of this lane's box rows / general rows
+  RT rvb[2], rvg[2];                          // penalties of this lane's box rows / general rows (f32 values)
 #pragma unroll
-  for (int f = 0; f < 2; ++f) { rvb[f] = eqb[f] ? P.rho_eq : P.rho; rvg[f] = P.rho; }
+  for (int f = 0; f < 2; ++f) { rvb[f] = (RT)(eqb[f] ? P.rho_eq : P.rho); rvg[f] = (RT)P.rho; }
   RT irvb[2], irvg[2];                        // reciprocals (refreshed with the penalties)
 #pragma unroll
-  for (int f = 0; f < 2; ++f) { irvb[f] = (RT)1 / (RT)rvb[f]; irvg[f] = (RT)1 / (RT)rvg[f]; }
-  float Vrow[NW];                             // row l of -(Gt + F)^-1 after the sweep
+  for (int f = 0; f < 2; ++f) { irvb[f] = (RT)1 / rvb[f]; irvg[f] = (RT)1 / rvg[f]; }
+  // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
+  // redone there instead of being hoisted into a second, f64, register copy that lives across the loop
+#define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
+  // row l of -(Gt + F)^-1 after the sweep, as float pairs: the sweep and the V mat-vec run on the
+  // packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two lanes of f32 per instruction)
+  f2 Vr[NW / 2];
+#define VROW(q) Vr[(q) >> 1][(q) & 1]
 
   auto factor = [&]() {
     if (dbg.prof) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
     // D_f = 2R + A' diag(rv) A, row c of both feet
     if (valid) {
-      sm.rvg[j][0][c] = rvg[0];
-      sm.rvg[j][1][c] = rvg[1];
+      sm.rvg[j][0][c] = (float)rvg[0];
+      sm.rvg[j][1][c] = (float)rvg[1];
     }
     __syncthreads();
+    // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so
+    // that none of it is live (= holds registers) during the iterations
+    int co = c;
+    asm volatile("" : "+v"(co));
+    float mkf[6];
+    double mkd[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { mkf[k] = (co == k) ? 1.f : 0.f; mkd[k] = (co == k) ? 1.0 : 0.0; }
+    const float lh = (float)P.lh, lt = (float)P.lt;
+    float ey[3], ez[3], muf[2], rf[2][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ey[a] = sm.eyz[a]; ez[a] = sm.eyz[3 + a]; }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      muf[f] = sm.muf[j][f];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) rf[f][a] = (float)sm.rr[j][f][a];
+    }
     double m3[3][6];                           // rows of D0, D1, Ka -> their inverses
     double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
     {
@@ -504,15 +539,23 @@ solve_kernel(const DevParams P, const int B,
       for (int f = 0; f < 2; ++f) {
         float G[6][6];
         general_rows(muf[f], ey, ez, lh, lt, G);
+        double wc[6];                          // rho_r * G[r][c]
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          float gc = 0.f;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) gc = fmaf(mkf[b], G[r][b], gc);
+          wc[r] = (double)sm.rvg[j][f][r] * (double)gc;
+        }
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           double s = 0.0;
 #pragma unroll
-          for (int r = 0; r < 6; ++r) s = fma((double)sm.rvg[j][f][r] * (double)gcol[f][r], (double)G[r][b], s);
+          for (int r = 0; r < 6; ++r) s = fma(wc[r], (double)G[r][b], s);
           m3[f][b] = fma(mkd[b], (double)R2v[f] + (double)rvb[f], s);
         }
 #pragma unroll
-        for (int b = 0; b < 6; ++b) (f == 0 ? sm.M0 : sm.M1)[j][c][b] = m3[f][b];
+        for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[f][b];
       }
     }
     __syncthreads();
@@ -522,7 +565,7 @@ solve_kernel(const DevParams P, const int B,
       for (int q = 0; q < 6; ++q) {
         double s = 0.0;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) s = fma(Tcol[p], sm.M1[j][p][q], s);
+        for (int p = 0; p < 6; ++p) s = fma(Tcol[p], sm.u.fac.M1[j][p][q], s);
         yq[q] = s;
       }
 #pragma unroll
@@ -537,7 +580,7 @@ solve_kernel(const DevParams P, const int B,
     sweep6<H, RT, 3>(m3, sm, valid, j, c);     // -> D0^-1, D1^-1, Ka^-1
     if (valid) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { sm.M0[j][c][b] = m3[0][b]; sm.M1[j][c][b] = m3[1][b]; sm.M2[j][c][b] = m3[2][b]; }
+      for (int b = 0; b < 6; ++b) { sm.u.fac.M0[j][c][b] = m3[0][b]; sm.u.fac.M1[j][c][b] = m3[1][b]; }
     }
     __syncthreads();
     // E = sum_f W_f D_f^-1 W_f',  W_f = [[r_f]x, I; I, 0]
@@ -575,7 +618,7 @@ solve_kernel(const DevParams P, const int B,
         for (int q = 0; q < 6; ++q) {
           double s = 0.0;
 #pragma unroll
-          for (int p = 0; p < 6; ++p) s = fma(Wrow[f][p], (f == 0 ? sm.M0 : sm.M1)[j][p][q], s);
+          for (int p = 0; p < 6; ++p) s = fma(Wrow[f][p], (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][p][q], s);
           yq[q] = s;
         }
 #pragma unroll
@@ -584,11 +627,11 @@ solve_kernel(const DevParams P, const int B,
           for (int q = 0; q < 6; ++q) e1[0][b] = fma(yq[q], Wm[f][b][q], e1[0][b]);
       }
     }
-    __syncthreads();                           // M0 (D0^-1) reads done: its slot now receives F
+    __syncthreads();                           // M0, M1 (D_f^-1) reads done: the slots now receive F and Ka^-1
     sweep6<H, RT, 1>(e1, sm, valid, j, c);     // -> F = E^-1
     if (valid) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.M0[j][c][b] = e1[0][b];
+      for (int b = 0; b < 6; ++b) { sm.u.fac.M0[j][c][b] = e1[0][b]; sm.u.fac.M1[j][c][b] = m3[2][b]; }
     }
     __syncthreads();
     if (valid) {
@@ -607,33 +650,18 @@ solve_kernel(const DevParams P, const int B,
         for (int b = 0; b < 6; ++b) {
           double s = 0.0;
 #pragma unroll
-          for (int p = 0; p < 6; ++p) s = fma(xq[p], sm.M0[j][p][b], s);
+          for (int p = 0; p < 6; ++p) s = fma(xq[p], sm.u.fac.M0[j][p][b], s);
           sm.L[j][f][c][b] = (float)s;
         }
       }
-      // Na = N Ka^-1 N', N_0 = I, N_1 = -T
-      double kt[6];                            // (Ka^-1 T')[c][b]
-      double tk[6];                            // (T Ka^-1)[c][b]
+      // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        double s = 0.0, s2 = 0.0;
+        double s2 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          s = fma(m3[2][q], Tm[b][q], s);
-          s2 = fma(Trow[q], sm.M2[j][q][b], s2);
-        }
-        kt[b] = s;
-        tk[b] = s2;
-      }
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        sm.Na[j][0][c][b] = (float)m3[2][b];
-        sm.Na[j][0][c][6 + b] = (float)(-kt[b]);
-        sm.Na[j][1][c][b] = (float)(-tk[b]);
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) s = fma(tk[q], Tm[b][q], s);
-        sm.Na[j][1][c][6 + b] = (float)s;
+        for (int q = 0; q < 6; ++q) s2 = fma(Trow[q], sm.u.fac.M1[j][q][b], s2);
+        sm.Kn[j][0][c][b] = (float)m3[2][b];
+        sm.Kn[j][1][c][b] = (float)s2;
       }
     }
     __syncthreads();
@@ -647,16 +675,16 @@ solve_kernel(const DevParams P, const int B,
         float v;
         if (c < 3) v = (b < 3) ? Grow[3 * j2 + (b < 3 ? b : 0)] : 0.f;
         else v = mkf[b] * Grow[j2];
-        Vrow[q] = v;
+        VROW(q) = v;
       }
       float fv[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) fv[b] = (float)sm.M0[j][c][b];
+      for (int b = 0; b < 6; ++b) fv[b] = (float)sm.u.fac.M0[j][c][b];
 #pragma unroll
       for (int j2 = 0; j2 < H; ++j2) {
         const float mj = (j2 == j) ? 1.f : 0.f;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) Vrow[6 * j2 + b] = fmaf(mj, fv[b], Vrow[6 * j2 + b]);
+        for (int b = 0; b < 6; ++b) VROW(6 * j2 + b) = fmaf(mj, fv[b], VROW(6 * j2 + b));
       }
     }
     // Groups of U steps are unrolled so the pivot column sits in the static register u; the register
@@ -671,38 +699,55 @@ solve_kernel(const DevParams P, const int B,
         if (valid) {
           int pos = l - k0;
           pos += (pos < 0) ? NW : 0;
-          buf[pos] = Vrow[u];
+          buf[pos] = VROW(u);
         }
         __syncthreads();
         if (valid) {
-          // fetch the whole pivot vector first (NW/4 back-to-back ds_read_b128, one wait), then compute:
-          // with one wave per SIMD nothing else hides the LDS latency
-          float pb[NW];
-#pragma unroll
-          for (int r = 0; r < NW; r += 4) {
-            const float4 q4 = *reinterpret_cast<const float4*>(&buf[r]);
-            pb[r] = q4.x; pb[r + 1] = q4.y; pb[r + 2] = q4.z; pb[r + 3] = q4.w;
-          }
-          const float ci = Vrow[u];
-          const float pinv = __builtin_amdgcn_rcpf(pb[u]);
+          // fetch the pivot vector first (back-to-back ds_read_b128, one wait), then compute: with one
+          // wave per SIMD nothing else hides the LDS latency.  (Chunked fetch costs less registers.)
+#ifdef BMPC_PIVOT_CHUNKS                     // for builds that target two waves per SIMD (256 registers)
+          constexpr int PB = (NW % 24 == 0) ? 24 : 20;
+#else
+          constexpr int PB = NW;
+#endif
+          static_assert(NW % PB == 0 && PB % 4 == 0 && U <= PB, "pivot chunk");
+          const float ci = VROW(u);
           const bool isp = (l == k0 + u);
           // the pivot lane rebuilds its row from the published COLUMN (buf), which re-symmetrises the
           // matrix at every pivot; scaling its own row instead lets f32 asymmetry grow and diverge
           const float sc = isp ? 0.f : 1.f;
-          const float t = isp ? -pinv : ci * pinv;
+          f2 t2 = {0.f, 0.f};
+          const f2 sc2 = {sc, sc};
+          float t = 0.f;
 #pragma unroll
-          for (int r = 0; r < NW; ++r) Vrow[r] = fmaf(-t, pb[r], sc * Vrow[r]);
-          Vrow[u] = t;
+          for (int r0 = 0; r0 < NW; r0 += PB) {
+            f2 pb[PB / 2];
+#pragma unroll
+            for (int r = 0; r < PB; r += 4) {
+              const float4 q4 = *reinterpret_cast<const float4*>(&buf[r0 + r]);
+              pb[r / 2] = f2{q4.x, q4.y};
+              pb[r / 2 + 1] = f2{q4.z, q4.w};
+            }
+            if (r0 == 0) {
+              const float pinv = __builtin_amdgcn_rcpf(pb[u >> 1][u & 1]);
+              t = isp ? -pinv : ci * pinv;
+              t2 = f2{t, t};
+            }
+#pragma unroll
+            for (int r = 0; r < PB / 2; ++r)
+              Vr[r0 / 2 + r] = __builtin_elementwise_fma(-t2, pb[r], sc2 * Vr[r0 / 2 + r]);
+          }
+          VROW(u) = t;
         }
       }
       if (valid) {                             // rotate left by U
-        float tmp[U];
+        f2 tmp[U / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) tmp[u] = Vrow[u];
+        for (int u = 0; u < U / 2; ++u) tmp[u] = Vr[u];
 #pragma unroll
-        for (int r = 0; r + U < NW; ++r) Vrow[r] = Vrow[r + U];
+        for (int r = 0; r + U / 2 < NW / 2; ++r) Vr[r] = Vr[r + U / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) Vrow[NW - U + u] = tmp[u];
+        for (int u = 0; u < U / 2; ++u) Vr[NW / 2 - U / 2 + u] = tmp[u];
       }
     }
     if (dbg.prof) t_sweep += clock64() - t_mark;
@@ -729,18 +774,21 @@ solve_kernel(const DevParams P, const int B,
     // --- E1: row residuals w = y + rho (A x - z), net wrench of x
     RT wb[2];
     if (valid) {
-      RT xblk[2][6];
+      RT xblk[2][6], gu[6];
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int b = 0; b < 6; ++b) xblk[f][b] = sm.xs[j][f][b];
 #pragma unroll
+      for (int b = 0; b < 6; ++b) gu[b] = sm.Gu[c][b];
+#pragma unroll
       for (int f = 0; f < 2; ++f) {
         RT axg = 0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) axg += (RT)grow[f][b] * xblk[f][b];
-        wb[f] = yb[f] + (RT)rvb[f] * (xo[f] - zb[f]);
-        sm.wg[j][f][c] = yg[f] + (RT)rvg[f] * (axg - zg[f]);
+        for (int b = 0; b < 6; ++b) axg += gu[b] * xblk[f][b];
+        axg += negmu[f] * xblk[f][2];
+        wb[f] = yb[f] + rvb[f] * (xo[f] - zb[f]);
+        sm.u.itv.wg[j][f][c] = yg[f] + rvg[f] * (axg - zg[f]);
       }
       RT val;
       if (c < 3) {
@@ -756,7 +804,7 @@ solve_kernel(const DevParams P, const int B,
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
         val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
-      sm.bw[l] = val;
+      sm.u.itv.bw[l] = val;
     }
     __syncthreads();
     // --- E2: wrench-space gradient gb = Gt b + qt
@@ -766,23 +814,34 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int j2 = 0; j2 < H; ++j2)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) g += (RT)Grow[3 * j2 + b] * sm.bw[6 * j2 + b];
+          for (int b = 0; b < 3; ++b) {
+            g += (RT)Grow[3 * j2 + b] * sm.u.itv.bw[6 * j2 + b];
+          }
       } else {
 #pragma unroll
-        for (int j2 = 0; j2 < H; ++j2) g += (RT)Grow[j2] * sm.bw[6 * j2 + c];
+        for (int j2 = 0; j2 < H; ++j2) {
+          g += (RT)Grow[j2] * sm.u.itv.bw[6 * j2 + c];
+        }
       }
-      sm.gb[l] = g;
+      sm.u.itv.gb[l] = g;
     }
     __syncthreads();
     // --- E3: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     if (valid) {
-      RT gt3[3] = {sm.gb[6 * j], sm.gb[6 * j + 1], sm.gb[6 * j + 2]};
-      RT gf3[3] = {sm.gb[6 * j + 3], sm.gb[6 * j + 4], sm.gb[6 * j + 5]};
+      RT gut[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
+      RT gt3[3] = {sm.u.itv.gb[6 * j], sm.u.itv.gb[6 * j + 1], sm.u.itv.gb[6 * j + 2]};
+      RT gf3[3] = {sm.u.itv.gb[6 * j + 3], sm.u.itv.gb[6 * j + 4], sm.u.itv.gb[6 * j + 5]};
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        RT r = (RT)R2v[f] * xo[f] + wb[f];
+        RT r = R2v[f] * xo[f] + wb[f];
+        RT wq[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) r += (RT)gcol[f][q] * sm.wg[j][f][q];
+        for (int q = 0; q < 6; ++q) wq[q] = sm.u.itv.wg[j][f][q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
+        r += cmu[f] * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
         RT wt;
         if (c < 3) {
           const RT rfd[3] = {sm.rr[j][f][0], sm.rr[j][f][1], sm.rr[j][f][2]};
@@ -792,7 +851,7 @@ solve_kernel(const DevParams P, const int B,
         } else {
           wt = mk3[0] * gt3[0] + mk3[1] * gt3[1] + mk3[2] * gt3[2];
         }
-        sm.r32[j][f][c] = (float)(r + wt);
+        sm.u.itv.r32[j][f][c] = (float)(r + wt);
       }
     }
     __syncthreads();
@@ -804,24 +863,23 @@ solve_kernel(const DevParams P, const int B,
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          rj[f][i] = sm.r32[j][f][i];
+          rj[f][i] = sm.u.itv.r32[j][f][i];
           s = fmaf(sm.L[j][f][i][c], rj[f][i], s);
         }
-      sm.beta[l] = s;
+      sm.u.itv.beta[l] = s;
     }
     __syncthreads();
     // --- E5: gamma = V beta   (Vrow holds -V)
     if (valid) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NW; q += 4) {
-        const float4 bq = *reinterpret_cast<const float4*>(&sm.beta[q]);
-        s0 = fmaf(Vrow[q], bq.x, s0);
-        s1 = fmaf(Vrow[q + 1], bq.y, s1);
-        s2 = fmaf(Vrow[q + 2], bq.z, s2);
-        s3 = fmaf(Vrow[q + 3], bq.w, s3);
+        const float4 bq = *reinterpret_cast<const float4*>(&sm.u.itv.beta[q]);
+        a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+        a1 = __builtin_elementwise_fma(Vr[q / 2 + 1], f2{bq.z, bq.w}, a1);
       }
-      sm.gam[l] = -((s0 + s1) + (s2 + s3));
+      const float s0 = a0.x, s1 = a0.y, s2 = a1.x, s3 = a1.y;
+      sm.u.itv.gam[l] = -((s0 + s1) + (s2 + s3));
     }
     __syncthreads();
     // --- E6: x~ = x - (Na r + L gamma)
@@ -829,18 +887,28 @@ solve_kernel(const DevParams P, const int B,
     if (valid) {
       float gm[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) gm[i] = sm.gam[6 * j + i];
+      for (int i = 0; i < 6; ++i) gm[i] = sm.u.itv.gam[6 * j + i];
+      // t = N' r = r_0 - T' r_1 ;  null-space part of x~: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
+      float tn[6];
+      {
+        const float d0 = drf[0], d1 = drf[1], d2 = drf[2];
+        tn[0] = rj[0][0] - rj[1][0] + (d1 * rj[1][5] - d2 * rj[1][4]);
+        tn[1] = rj[0][1] - rj[1][1] + (d2 * rj[1][3] - d0 * rj[1][5]);
+        tn[2] = rj[0][2] - rj[1][2] + (d0 * rj[1][4] - d1 * rj[1][3]);
+        tn[3] = rj[0][3] - rj[1][3];
+        tn[4] = rj[0][4] - rj[1][4];
+        tn[5] = rj[0][5] - rj[1][5];
+      }
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         float s = 0.f;
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int i = 0; i < 6; ++i) s = fmaf(sm.Na[j][f][c][6 * g + i], rj[g][i], s);
+        for (int i = 0; i < 6; ++i) s = fmaf(sm.Kn[j][f][c][i], tn[i], s);
+        if (f == 1) s = -s;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s = fmaf(sm.L[j][f][c][i], gm[i], s);
         xto[f] = xo[f] - (RT)s;
-        sm.xt[j][f][c] = xto[f];
+        sm.u.itv.xt[j][f][c] = xto[f];
       }
     }
     __syncthreads();
@@ -848,21 +916,25 @@ solve_kernel(const DevParams P, const int B,
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
     int nanl = 0;                              // fmaxf drops NaNs: track them explicitly
     if (valid) {
+      RT gu7[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) gu7[b] = sm.Gu[c][b];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         RT xtb[6];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) xtb[b] = sm.xt[j][f][b];
+        for (int b = 0; b < 6; ++b) xtb[b] = sm.u.itv.xt[j][f][b];
         RT ztg = 0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) ztg += (RT)grow[f][b] * xtb[b];
+        for (int b = 0; b < 6; ++b) ztg += gu7[b] * xtb[b];
+        ztg += negmu[f] * xtb[2];
         const RT ztb = xto[f];
         // box row
         {
           const RT zr = alpha * ztb + (1 - alpha) * zb[f];
           const RT cand = zr + yb[f] * irvb[f];
-          const RT zn = min_rt(max_rt(cand, (RT)lb[f]), (RT)ub[f]);
-          yb[f] += (RT)rvb[f] * (zr - zn);
+          const RT zn = min_rt(max_rt(cand, lb[f]), ub[f]);
+          yb[f] += rvb[f] * (zr - zn);
           zb[f] = zn;
           rp = fmaxf(rp, fabsf((float)(ztb - zn)));
           nz = fmaxf(nz, fabsf((float)ztb));
@@ -872,7 +944,7 @@ solve_kernel(const DevParams P, const int B,
           const RT zr = alpha * ztg + (1 - alpha) * zg[f];
           const RT cand = zr + yg[f] * irvg[f];
           const RT zn = min_rt(cand, (RT)0);
-          yg[f] += (RT)rvg[f] * (zr - zn);
+          yg[f] += rvg[f] * (zr - zn);
           zg[f] = zn;
           rp = fmaxf(rp, fabsf((float)(ztg - zn)));
           nz = fmaxf(nz, fabsf((float)ztg));
@@ -904,13 +976,14 @@ solve_kernel(const DevParams P, const int B,
       if (valid) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          const bool actb = (zb[f] <= (RT)lb[f] || zb[f] >= (RT)ub[f]) && yb[f] != (RT)0;
+          const bool actb = (zb[f] <= lb[f] || zb[f] >= ub[f]) && yb[f] != (RT)0;
           const bool actg = (zg[f] >= (RT)0) && yg[f] != (RT)0;
           // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
           const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-          nb[f] = eqb[f] ? P.rho_eq : (actb ? fminf(rvb[f] * P.kappa, hib) : fmaxf(rvb[f] / P.kappa, P.rho_lo));
-          ng[f] = actg ? fminf(rvg[f] * P.kappa, hig) : fmaxf(rvg[f] / P.kappa, P.rho_lo);
-          changed |= (nb[f] != rvb[f]) | (ng[f] != rvg[f]);
+          const float ob = (float)rvb[f], og = (float)rvg[f];
+          nb[f] = eqb[f] ? P.rho_eq : (actb ? fminf(ob * P.kappa, hib) : fmaxf(ob / P.kappa, P.rho_lo));
+          ng[f] = actg ? fminf(og * P.kappa, hig) : fmaxf(og / P.kappa, P.rho_lo);
+          changed |= (nb[f] != ob) | (ng[f] != og);
         }
       }
       changed = __syncthreads_or(changed);
@@ -918,8 +991,8 @@ solve_kernel(const DevParams P, const int B,
         if (valid) {
 #pragma unroll
           for (int f = 0; f < 2; ++f) {
-            rvb[f] = nb[f]; rvg[f] = ng[f];
-            irvb[f] = (RT)1 / (RT)nb[f]; irvg[f] = (RT)1 / (RT)ng[f];
+            rvb[f] = (RT)nb[f]; rvg[f] = (RT)ng[f];
+            irvb[f] = (RT)1 / rvb[f]; irvg[f] = (RT)1 / rvg[f];
           }
         }
         need_factor = true;
@@ -959,7 +1032,7 @@ solve_kernel(const DevParams P, const int B,
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
         val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
-      sm.bw[l] = val;
+      sm.u.itv.bw[l] = val;
     }
     __syncthreads();
     if (valid) {
@@ -968,30 +1041,30 @@ solve_kernel(const DevParams P, const int B,
       if (c < 3) {
         const int a = c;
         // euler: s + sum_{j2 < i} Me[i][j2] tau_j2 ; omega: w_fb + dt sum_{j2 <= i} Iw_j2 tau_j2
-        RT e = sm.err[i][a], w = sm.err[i][6 + a];
+        RT e = sm.s0[i][a], w = sm.s0[i][6 + a];
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
-          const RT t3[3] = {sm.bw[6 * j2], sm.bw[6 * j2 + 1], sm.bw[6 * j2 + 2]};
+          const RT t3[3] = {sm.u.itv.bw[6 * j2], sm.u.itv.bw[6 * j2 + 1], sm.u.itv.bw[6 * j2 + 2]};
           if (j2 < i) {
             const float* m1 = sm.Me[pair_index(i, j2)];
             e += (RT)m1[3 * a] * t3[0] + (RT)m1[3 * a + 1] * t3[1] + (RT)m1[3 * a + 2] * t3[2];
           }
           w += dt * (sm.Iw[j2][3 * a] * t3[0] + sm.Iw[j2][3 * a + 1] * t3[1] + sm.Iw[j2][3 * a + 2] * t3[2]);
         }
-        so[a] = (float)(e + sm.xref[i][a]);
-        so[6 + a] = (float)(w + sm.xref[i][6 + a]);
+        so[a] = (float)e;
+        so[6 + a] = (float)w;
       } else {
         const int a = c - 3;
-        RT p = sm.err[i][3 + a], v = sm.err[i][9 + a];
+        RT p = sm.s0[i][3 + a], v = sm.s0[i][9 + a];
         const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
-          const RT fa = sm.bw[6 * j2 + 3 + a];
+          const RT fa = sm.u.itv.bw[6 * j2 + 3 + a];
           p += kp * (RT)(i - j2) * fa;
           v += kvv * fa;
         }
-        so[3 + a] = (float)(p + sm.xref[i][3 + a]);
-        so[9 + a] = (float)(v + sm.xref[i][9 + a]);
+        so[3 + a] = (float)p;
+        so[9 + a] = (float)v;
       }
       if (c == 0) so[12] = 1.0f;
     }
