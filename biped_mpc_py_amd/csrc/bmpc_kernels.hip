@@ -28,6 +28,35 @@ namespace bmpc {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Explicit live-range splitting.  With one wave per SIMD the 256 accumulation registers are free;
+// the values that merely have to survive the register-hungry factorisation are moved there by hand
+// and back afterwards (2 moves per factorisation).  Left to the allocator they get an AGPR home for
+// their whole life and pay a copy at every use in every iteration.
+struct Parked64 { int lo, hi; };
+__device__ __forceinline__ void park(float v, float& slot) {
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot) : "v"(v));
+}
+__device__ __forceinline__ void unpark(float& v, const float& slot) {
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot));
+}
+__device__ __forceinline__ void park(double v, Parked64& slot) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot.lo) : "v"(lo));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot.hi) : "v"(hi));
+}
+__device__ __forceinline__ void unpark(double& v, const Parked64& slot) {
+  int lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(slot.lo));
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(slot.hi));
+  v = __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void park(float v, Parked64& slot) {     // RT = float builds
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot.lo) : "v"(v));
+}
+__device__ __forceinline__ void unpark(float& v, const Parked64& slot) {
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot.lo));
+}
+
 struct DevParams {
   int h, half, max_iter, check_every, adapt_start, adapt_every, max_refactor, pad0;
   double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
@@ -64,7 +93,6 @@ struct FacScratch {
 template <int H, typename RT>
 struct IterScratch {
   static constexpr int NW = Dims<H>::NW;
-  RT xt[H][2][6];            // x tilde
   RT wg[H][2][6];            // y + rho (A x - z) on the general rows
   RT bw[NW];                 // net wrench of x
   RT gb[NW];                 // wrench-space gradient Gt b + qt
@@ -88,6 +116,8 @@ struct alignas(16) Smem {
   // block-diagonal part of K^-1
   alignas(16) float L[H][2][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
   alignas(16) float Kn[H][2][6][6];     // [0]: Ka^-1, [1]: T Ka^-1   (N Ka^-1 N' applied as N (Ka^-1 (N' r)))
+  alignas(16) float GK[H][2][6][6];     // G_f Kn_f and G_f L_f: the general rows of the step d, from (t, gamma)
+  alignas(16) float GL[H][2][6][6];
   // step data
   RT Iw[H][9];               // world inverse inertia
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
@@ -431,7 +461,7 @@ solve_kernel(const DevParams P, const int B,
   // f32 copy + hoisted conversion doubles their register footprint.
   RT lb[2], ub[2], R2v[2];
   bool eqb[2];
-  RT negmu[2], cmu[2];                        // -mu_f if this lane's general row is a friction row / if its variable is f_z
+  RT cmu[2];                                  // -mu_f if this lane's variable is f_z (column 2 of the friction rows)
   float drf[3];                               // r_0 - r_1 of this step
   {
     float ey[3], ez[3];                       // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
@@ -465,7 +495,6 @@ solve_kernel(const DevParams P, const int B,
       lb[f] = (RT)lbf;
       eqb[f] = lbf == ubf;
       R2v[f] = (RT)(float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
-      negmu[f] = c < 4 ? (RT)(-muf) : (RT)0;
       cmu[f] = c == 2 ? (RT)(-muf) : (RT)0;
     }
 #pragma unroll
@@ -487,6 +516,7 @@ solve_kernel(const DevParams P, const int B,
   f2 Vr[NW / 2];
 #define VROW(q) Vr[(q) >> 1][(q) & 1]
 
+  float gpark[3 * H];                         // Grow while the block algebra runs
   auto factor = [&]() {
     if (dbg.prof) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
@@ -665,7 +695,34 @@ solve_kernel(const DevParams P, const int B,
       }
     }
     __syncthreads();
+    if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float G[6][6], gr[6];
+        general_rows(muf[f], ey, ez, lh, lt, G);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          float g1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) g1 = fmaf(mkf[r], G[r][b], g1);
+          gr[b] = g1;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          float gk = 0.f, gl = 0.f;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            gk = fmaf(gr[b], sm.Kn[j][f][b][i], gk);
+            gl = fmaf(gr[b], sm.L[j][f][b][i], gl);
+          }
+          sm.GK[j][f][c][i] = gk;
+          sm.GL[j][f][c][i] = gl;
+        }
+      }
+    }
     if (dbg.prof) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
+#pragma unroll
+    for (int q = 0; q < 3 * H; ++q) unpark(Grow[q], gpark[q]);
     // K' row = Gt row + F row on the own step; then symmetric sweep with a rotating register file:
     // at step k register r holds column (r + k) mod NW, so the pivot column is always register 0.
     if (valid) {
@@ -757,22 +814,23 @@ solve_kernel(const DevParams P, const int B,
   bool need_factor = true;
 
   // ------------------------------------------------------------------ E. ADMM iterations
+  // A lane carries, next to its variables and rows, two products of the iterate that are linear in
+  // it and so follow the relaxation x <- alpha x~ + (1 - alpha) x without an exchange:
+  //   axg_f = (G_f x_f)[c]   : x~ = x - d with d_f = N_f Ka^-1 N' r + L_f gamma, so G_f x~ = axg - (GK tn + GL gamma)
+  //   bwl   = (W x)[l]       : W N = 0 and W L = sum_f W_f D_f^-1 W_f' F = I, so W x~ = bw - gamma exactly
+  // The f32 rounding of these corrections vanishes with the step (r, gamma -> 0) and both carried values
+  // are rebuilt exactly from x at every stopping test, so the fixed point is unchanged.
   RT xo[2] = {0, 0};                          // own variables
   RT zb[2] = {0, 0}, zg[2] = {0, 0}, yb[2] = {0, 0}, yg[2] = {0, 0};
-  if (valid) { sm.xs[j][0][c] = 0; sm.xs[j][1][c] = 0; }
+  RT axg[2] = {0, 0}, bwl = 0;
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   float res_p = 0.f, res_s = 0.f;
 
-#pragma unroll 1
-  for (it = 0; it < P.max_iter;) {
-    if (need_factor) {                         // workgroup-uniform
-      factor();
-      ++nfac;
-      need_factor = false;
-    }
-    // --- E1: row residuals w = y + rho (A x - z), net wrench of x
-    RT wb[2];
+  // exact axg, bwl from x (exchange through LDS); all threads call
+  auto refresh = [&]() {
+    if (valid) { sm.xs[j][0][c] = xo[0]; sm.xs[j][1][c] = xo[1]; }
+    __syncthreads();
     if (valid) {
       RT xblk[2][6], gu[6];
 #pragma unroll
@@ -783,14 +841,12 @@ solve_kernel(const DevParams P, const int B,
       for (int b = 0; b < 6; ++b) gu[b] = sm.Gu[c][b];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        RT axg = 0;
+        RT a = 0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) axg += gu[b] * xblk[f][b];
-        axg += negmu[f] * xblk[f][2];
-        wb[f] = yb[f] + rvb[f] * (xo[f] - zb[f]);
-        sm.u.itv.wg[j][f][c] = yg[f] + rvg[f] * (axg - zg[f]);
+        for (int b = 0; b < 6; ++b) a += gu[b] * xblk[f][b];
+        const RT negmu = c < 4 ? -(RT)sm.muf[j][f] : (RT)0;
+        axg[f] = a + negmu * xblk[f][2];
       }
-      RT val;
       if (c < 3) {
         RT t0[3], t1[3];
         const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
@@ -799,34 +855,75 @@ solve_kernel(const DevParams P, const int B,
         cross3(r1, &xblk[1][0], t1);
         RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
                     t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
-        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
+        bwl = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       } else {
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
-        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
+        bwl = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
-      sm.u.itv.bw[l] = val;
+    }
+  };
+
+#pragma unroll 1
+  for (it = 0; it < P.max_iter;) {
+    if (need_factor) {                         // workgroup-uniform
+      // park what the factorisation does not touch (see park() above)
+      Parked64 pk[29];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        park(xo[f], pk[f]); park(zb[f], pk[2 + f]); park(zg[f], pk[4 + f]); park(yb[f], pk[6 + f]);
+        park(yg[f], pk[8 + f]); park(axg[f], pk[10 + f]); park(irvb[f], pk[12 + f]); park(irvg[f], pk[14 + f]);
+        park(lb[f], pk[16 + f]); park(ub[f], pk[18 + f]); park(cmu[f], pk[20 + f]);
+      }
+      park(bwl, pk[22]); park(qt, pk[23]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) park(mk3[k], pk[24 + k]);
+      float pkd[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) park(drf[k], pkd[k]);
+#pragma unroll
+      for (int q = 0; q < 3 * H; ++q) park(Grow[q], gpark[q]);
+      factor();
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        unpark(xo[f], pk[f]); unpark(zb[f], pk[2 + f]); unpark(zg[f], pk[4 + f]); unpark(yb[f], pk[6 + f]);
+        unpark(yg[f], pk[8 + f]); unpark(axg[f], pk[10 + f]); unpark(irvb[f], pk[12 + f]); unpark(irvg[f], pk[14 + f]);
+        unpark(lb[f], pk[16 + f]); unpark(ub[f], pk[18 + f]); unpark(cmu[f], pk[20 + f]);
+      }
+      unpark(bwl, pk[22]); unpark(qt, pk[23]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) unpark(mk3[k], pk[24 + k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) unpark(drf[k], pkd[k]);
+      ++nfac;
+      need_factor = false;
+    }
+    // --- P0: row residuals w = y + rho (A x - z); publish them and the net wrench
+    RT wb[2];
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        wb[f] = yb[f] + rvb[f] * (xo[f] - zb[f]);
+        sm.u.itv.wg[j][f][c] = yg[f] + rvg[f] * (axg[f] - zg[f]);
+      }
+      sm.u.itv.bw[l] = bwl;
     }
     __syncthreads();
-    // --- E2: wrench-space gradient gb = Gt b + qt
+    // --- P1: wrench-space gradient gb = Gt b + qt
     if (valid) {
       RT g = qt;
       if (c < 3) {
 #pragma unroll
         for (int j2 = 0; j2 < H; ++j2)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            g += (RT)Grow[3 * j2 + b] * sm.u.itv.bw[6 * j2 + b];
-          }
+          for (int b = 0; b < 3; ++b) g += (RT)Grow[3 * j2 + b] * sm.u.itv.bw[6 * j2 + b];
       } else {
 #pragma unroll
-        for (int j2 = 0; j2 < H; ++j2) {
-          g += (RT)Grow[j2] * sm.u.itv.bw[6 * j2 + c];
-        }
+        for (int j2 = 0; j2 < H; ++j2) g += (RT)Grow[j2] * sm.u.itv.bw[6 * j2 + c];
       }
       sm.u.itv.gb[l] = g;
     }
     __syncthreads();
-    // --- E3: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
+    // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     if (valid) {
       RT gut[6];
 #pragma unroll
@@ -855,7 +952,7 @@ solve_kernel(const DevParams P, const int B,
       }
     }
     __syncthreads();
-    // --- E4: beta = L' r
+    // --- P3: beta = L' r
     float rj[2][6];
     if (valid) {
       float s = 0.f;
@@ -869,7 +966,8 @@ solve_kernel(const DevParams P, const int B,
       sm.u.itv.beta[l] = s;
     }
     __syncthreads();
-    // --- E5: gamma = V beta   (Vrow holds -V)
+    // --- P4: gamma = V beta   (Vr holds -V)
+    float gown = 0.f;
     if (valid) {
       f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
@@ -878,17 +976,18 @@ solve_kernel(const DevParams P, const int B,
         a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
         a1 = __builtin_elementwise_fma(Vr[q / 2 + 1], f2{bq.z, bq.w}, a1);
       }
-      const float s0 = a0.x, s1 = a0.y, s2 = a1.x, s3 = a1.y;
-      sm.u.itv.gam[l] = -((s0 + s1) + (s2 + s3));
+      gown = -((a0.x + a0.y) + (a1.x + a1.y));
+      sm.u.itv.gam[l] = gown;
     }
     __syncthreads();
-    // --- E6: x~ = x - (Na r + L gamma)
-    RT xto[2];
+    // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
+    int nanl = 0;                              // fmaxf drops NaNs: track them explicitly
     if (valid) {
       float gm[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) gm[i] = sm.u.itv.gam[6 * j + i];
-      // t = N' r = r_0 - T' r_1 ;  null-space part of x~: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
+      // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
       float tn[6];
       {
         const float d0 = drf[0], d1 = drf[1], d2 = drf[2];
@@ -901,34 +1000,21 @@ solve_kernel(const DevParams P, const int B,
       }
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        float s = 0.f;
+        float s = 0.f, sg = 0.f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s = fmaf(sm.Kn[j][f][c][i], tn[i], s);
-        if (f == 1) s = -s;
+        for (int i = 0; i < 6; ++i) {
+          s = fmaf(sm.Kn[j][f][c][i], tn[i], s);
+          sg = fmaf(sm.GK[j][f][c][i], tn[i], sg);
+        }
+        if (f == 1) { s = -s; sg = -sg; }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s = fmaf(sm.L[j][f][c][i], gm[i], s);
-        xto[f] = xo[f] - (RT)s;
-        sm.u.itv.xt[j][f][c] = xto[f];
-      }
-    }
-    __syncthreads();
-    // --- E7: z~ = A x~, relaxation, projection, dual update
-    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
-    int nanl = 0;                              // fmaxf drops NaNs: track them explicitly
-    if (valid) {
-      RT gu7[6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) gu7[b] = sm.Gu[c][b];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        RT xtb[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) xtb[b] = sm.u.itv.xt[j][f][b];
-        RT ztg = 0;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) ztg += gu7[b] * xtb[b];
-        ztg += negmu[f] * xtb[2];
-        const RT ztb = xto[f];
+        for (int i = 0; i < 6; ++i) {
+          s = fmaf(sm.L[j][f][c][i], gm[i], s);
+          sg = fmaf(sm.GL[j][f][c][i], gm[i], sg);
+        }
+        const RT xto = xo[f] - (RT)s;
+        const RT ztg = axg[f] - (RT)sg;
+        const RT ztb = xto;
         // box row
         {
           const RT zr = alpha * ztb + (1 - alpha) * zb[f];
@@ -949,17 +1035,18 @@ solve_kernel(const DevParams P, const int B,
           rp = fmaxf(rp, fabsf((float)(ztg - zn)));
           nz = fmaxf(nz, fabsf((float)ztg));
         }
-        nanl |= !(xto[f] == xto[f]);
-        rs = fmaxf(rs, fabsf((float)(xto[f] - xo[f])));
-        nx = fmaxf(nx, fabsf((float)xto[f]));
-        xo[f] = alpha * xto[f] + (1 - alpha) * xo[f];
-        sm.xs[j][f][c] = xo[f];
+        nanl |= !(xto == xto);
+        rs = fmaxf(rs, fabsf((float)(xto - xo[f])));
+        nx = fmaxf(nx, fabsf((float)xto));
+        xo[f] = alpha * xto + (1 - alpha) * xo[f];
+        axg[f] = alpha * ztg + (1 - alpha) * axg[f];
       }
+      bwl -= alpha * (RT)gown;
     }
     ++it;
-    __syncthreads();
-    // --- stopping test (workgroup-uniform)
+    // --- stopping test (workgroup-uniform); the carried products are rebuilt from x first
     if (it % P.check_every == 0 || it == P.max_iter) {
+      refresh();
       float v4[4] = {rp, rs, nz, nx};
       block_max4<NT>(v4, sm.red);
       res_p = v4[0];
@@ -999,6 +1086,7 @@ solve_kernel(const DevParams P, const int B,
       }
     }
   }
+  if (valid) { sm.xs[j][0][c] = xo[0]; sm.xs[j][1][c] = xo[1]; }   // for the state roll-out below
 
   // ------------------------------------------------------------------ F. outputs (REF:300-304)
   if (valid) {
