@@ -70,7 +70,7 @@ struct DebugOut {            // all nullable, fp64, device pointers
   double* foot_ref;          // [B][H][6]
   double* Gt;                // [B][6H][6H]
   double* qt;                // [B][6H]
-  long long* prof;           // [B][8] cycle stamps (diagnostic builds / tests only)
+  long long* prof;           // [B][16] cycle stamps (diagnostics / tools only)
   int assemble_only;
 };
 
@@ -94,7 +94,7 @@ template <int H, typename RT>
 struct IterScratch {
   static constexpr int NW = Dims<H>::NW;
   RT wg[H][2][6];            // y + rho (A x - z) on the general rows
-  RT bw[NW];                 // net wrench of x
+  alignas(16) RT bwT[6][H];  // net wrench of x, component-major: a lane reads its 3 H inputs of Gt contiguously
   RT gb[NW];                 // wrench-space gradient Gt b + qt
   alignas(16) float r32[H][2][6];   // KKT residual, control space
   alignas(16) float beta[NW];
@@ -133,14 +133,25 @@ struct alignas(16) Smem {
 
 __device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
 
-// max over the workgroup of up to 4 values at once.
+// max over the workgroup of 4 NON-NEGATIVE floats (or NaN) at once.  The order of such floats is
+// the order of their bit patterns, with NaN above everything, so the reduction is an unsigned max:
+// six DPP steps per value inside a wave (shifts read 0 = the neutral element where a source lane does
+// not exist), then the waves of a larger workgroup combine through LDS.  NaNs propagate.
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+#define BMPC_DPP_MAX(ctrl) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, true); v = v > o ? v : o; }
+  BMPC_DPP_MAX(0x111)   // row_shr:1
+  BMPC_DPP_MAX(0x112)   // row_shr:2
+  BMPC_DPP_MAX(0x114)   // row_shr:4
+  BMPC_DPP_MAX(0x118)   // row_shr:8   -> lane 15 of each row holds the row maximum
+  BMPC_DPP_MAX(0x142)   // row_bcast:15 -> lane 31 / 63: rows 0-1 / 2-3
+  BMPC_DPP_MAX(0x143)   // row_bcast:31 -> lane 63: whole wave
+#undef BMPC_DPP_MAX
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 template <int NT>
 __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64]) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v[q] = fmaxf(v[q], __shfl_xor(v[q], o, 64));
-  }
+  for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(wave_umax(__float_as_uint(v[q])));
   if constexpr (NT > 64) {
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
@@ -150,10 +161,10 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float m = red[q][0];
+      unsigned m = __float_as_uint(red[q][0]);
 #pragma unroll
-      for (int w2 = 1; w2 < NT / 64; ++w2) m = fmaxf(m, red[q][w2]);
-      v[q] = m;
+      for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
+      v[q] = __uint_as_float(m);
     }
     __syncthreads();
   }
@@ -246,6 +257,8 @@ solve_kernel(const DevParams P, const int B,
   const int inst = blockIdx.x;
   if (inst >= B) return;
   long long t_start = 0, t_setup = 0, t_blocks = 0, t_sweep = 0, t_mark = 0;
+  long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+#define BMPC_STAMP(k) if (dbg.prof) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
   if (dbg.prof) t_start = clock64();
   const int l = threadIdx.x;
   const bool valid = l < NW;
@@ -382,7 +395,10 @@ solve_kernel(const DevParams P, const int B,
   __syncthreads();
 
   // ------------------------------------------------------------------ B. wrench-space Hessian row
-  float Grow[3 * H];          // torque lanes: Gt[(j,a)][(j2,b<3)] at 3 j2 + b ; force lanes: Gt[(j,a)][(j2,a)] at j2
+  // Row of Gt against one component group of the wrench (torque lanes: tau, force lanes: F), laid out
+  // [b][j2] like bwT so that P1 is the same straight-line code for every lane:
+  // torque lane (j,a): Gt[(j,a)][(j2,b)] at b H + j2 ; force lane (j,3+a): Gt[(j,3+a)][(j2,3+a)] at a H + j2, zeros elsewhere
+  float Grow[3 * H];
   RT qt = 0;
 #pragma unroll
   for (int q = 0; q < 3 * H; ++q) Grow[q] = 0.f;
@@ -414,7 +430,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
           for (int q = 0; q < 3; ++q) s += nw[q] * dt * sm.Iw[j2][3 * q + b];
           const RT gval = 2 * (acc[b] + cnt * s);
-          Grow[3 * j2 + b] = (float)gval;
+          Grow[b * H + j2] = (float)gval;
           if (dbg.Gt) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + b] = (double)gval;
         }
       }
@@ -440,7 +456,8 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll 1
         for (int i = mx; i < H; ++i) s2 += (RT)((i - j) * (i - j2));
         const RT gval = 2 * ((RT)P.Q[3 + a] * kp * kp * s2 + (RT)P.Q[9 + a] * kvv * kvv * (RT)(H - mx));
-        Grow[j2] = (float)gval;
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2) Grow[a2 * H + j2] = (a2 == a) ? (float)gval : 0.f;
         if (dbg.Gt) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + 3 + a] = (double)gval;
       }
       RT s = 0;
@@ -730,8 +747,8 @@ solve_kernel(const DevParams P, const int B,
       for (int q = 0; q < NW; ++q) {
         const int j2 = q / 6, b = q % 6;
         float v;
-        if (c < 3) v = (b < 3) ? Grow[3 * j2 + (b < 3 ? b : 0)] : 0.f;
-        else v = mkf[b] * Grow[j2];
+        if (c < 3) v = (b < 3) ? Grow[(b < 3 ? b : 0) * H + j2] : 0.f;
+        else v = (b < 3) ? 0.f : Grow[(b < 3 ? 0 : b - 3) * H + j2];   // zero unless b == c
         VROW(q) = v;
       }
       float fv[6];
@@ -825,6 +842,9 @@ solve_kernel(const DevParams P, const int B,
   RT axg[2] = {0, 0}, bwl = 0;
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
+  int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
+  int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
+  while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
   float res_p = 0.f, res_s = 0.f;
 
   // exact axg, bwl from x (exchange through LDS); all threads call
@@ -897,6 +917,7 @@ solve_kernel(const DevParams P, const int B,
       ++nfac;
       need_factor = false;
     }
+    if (dbg.prof) t_last = clock64();
     // --- P0: row residuals w = y + rho (A x - z); publish them and the net wrench
     RT wb[2];
     if (valid) {
@@ -905,24 +926,29 @@ solve_kernel(const DevParams P, const int B,
         wb[f] = yb[f] + rvb[f] * (xo[f] - zb[f]);
         sm.u.itv.wg[j][f][c] = yg[f] + rvg[f] * (axg[f] - zg[f]);
       }
-      sm.u.itv.bw[l] = bwl;
+      sm.u.itv.bwT[c][j] = bwl;
     }
     __syncthreads();
+    BMPC_STAMP(0)
     // --- P1: wrench-space gradient gb = Gt b + qt
     if (valid) {
-      RT g = qt;
-      if (c < 3) {
+      static_assert(H % 2 == 0, "P1 reads the wrench in groups of 6");
+      // 3 H doubles of the lane's component group, 3 independent accumulation chains
+      const RT* bsrc = &sm.u.itv.bwT[c < 3 ? 0 : 3][0];
+      RT g0 = qt, g1 = 0, g2 = 0;
 #pragma unroll
-        for (int j2 = 0; j2 < H; ++j2)
+      for (int q = 0; q < 3 * H; q += 6) {
+        RT v[6];
 #pragma unroll
-          for (int b = 0; b < 3; ++b) g += (RT)Grow[3 * j2 + b] * sm.u.itv.bw[6 * j2 + b];
-      } else {
-#pragma unroll
-        for (int j2 = 0; j2 < H; ++j2) g += (RT)Grow[j2] * sm.u.itv.bw[6 * j2 + c];
+        for (int k = 0; k < 6; ++k) v[k] = bsrc[q + k];
+        g0 += (RT)Grow[q] * v[0];     g1 += (RT)Grow[q + 1] * v[1]; g2 += (RT)Grow[q + 2] * v[2];
+        g0 += (RT)Grow[q + 3] * v[3]; g1 += (RT)Grow[q + 4] * v[4]; g2 += (RT)Grow[q + 5] * v[5];
       }
+      const RT g = g0 + (g1 + g2);
       sm.u.itv.gb[l] = g;
     }
     __syncthreads();
+    BMPC_STAMP(1)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     if (valid) {
       RT gut[6];
@@ -952,6 +978,7 @@ solve_kernel(const DevParams P, const int B,
       }
     }
     __syncthreads();
+    BMPC_STAMP(2)
     // --- P3: beta = L' r
     float rj[2][6];
     if (valid) {
@@ -966,6 +993,7 @@ solve_kernel(const DevParams P, const int B,
       sm.u.itv.beta[l] = s;
     }
     __syncthreads();
+    BMPC_STAMP(3)
     // --- P4: gamma = V beta   (Vr holds -V)
     float gown = 0.f;
     if (valid) {
@@ -980,9 +1008,10 @@ solve_kernel(const DevParams P, const int B,
       sm.u.itv.gam[l] = gown;
     }
     __syncthreads();
+    BMPC_STAMP(4)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
-    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
-    int nanl = 0;                              // fmaxf drops NaNs: track them explicitly
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
+    const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
     if (valid) {
       float gm[6];
 #pragma unroll
@@ -1022,8 +1051,10 @@ solve_kernel(const DevParams P, const int B,
           const RT zn = min_rt(max_rt(cand, lb[f]), ub[f]);
           yb[f] += rvb[f] * (zr - zn);
           zb[f] = zn;
-          rp = fmaxf(rp, fabsf((float)(ztb - zn)));
-          nz = fmaxf(nz, fabsf((float)ztb));
+          if (check_now) {
+            rp = fmaxf(rp, fabsf((float)(ztb - zn)));
+            nz = fmaxf(nz, fabsf((float)ztb));
+          }
         }
         // general row: l = -inf, u = 0
         {
@@ -1032,32 +1063,39 @@ solve_kernel(const DevParams P, const int B,
           const RT zn = min_rt(cand, (RT)0);
           yg[f] += rvg[f] * (zr - zn);
           zg[f] = zn;
-          rp = fmaxf(rp, fabsf((float)(ztg - zn)));
-          nz = fmaxf(nz, fabsf((float)ztg));
+          if (check_now) {
+            rp = fmaxf(rp, fabsf((float)(ztg - zn)));
+            nz = fmaxf(nz, fabsf((float)ztg));
+          }
         }
-        nanl |= !(xto == xto);
-        rs = fmaxf(rs, fabsf((float)(xto - xo[f])));
-        nx = fmaxf(nx, fabsf((float)xto));
+        if (check_now) {
+          rs = fmaxf(rs, fabsf((float)(xto - xo[f])));
+          // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
+          nx = (xto == xto) ? fmaxf(nx, fabsf((float)xto)) : __builtin_inff();
+        }
         xo[f] = alpha * xto + (1 - alpha) * xo[f];
         axg[f] = alpha * ztg + (1 - alpha) * axg[f];
       }
       bwl -= alpha * (RT)gown;
     }
     ++it;
+    BMPC_STAMP(5)
     // --- stopping test (workgroup-uniform); the carried products are rebuilt from x first
-    if (it % P.check_every == 0 || it == P.max_iter) {
+    if (check_now) {
+      next_check += P.check_every;
       refresh();
       float v4[4] = {rp, rs, nz, nx};
       block_max4<NT>(v4, sm.red);
       res_p = v4[0];
       res_s = v4[1];
-      const bool bad = __syncthreads_or(nanl) || !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
+      const bool bad = !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
       if (bad) { status = 2; break; }
       if (v4[0] <= P.eps_pri * fmaxf(1.f, v4[2]) && v4[1] <= P.eps_dua * fmaxf(1.f, v4[3])) { status = 0; break; }
     }
     // --- penalty re-classification by the current active set
-    if (P.adapt_every > 0 && it >= P.adapt_start && (it - P.adapt_start) % P.adapt_every == 0 &&
-        nfac <= P.max_refactor) {
+    if (it == next_adapt) {
+      next_adapt += P.adapt_every;
+      if (nfac <= P.max_refactor) {
       int changed = 0;
       float nb[2], ng[2];
       if (valid) {
@@ -1084,7 +1122,9 @@ solve_kernel(const DevParams P, const int B,
         }
         need_factor = true;
       }
+      }
     }
+    BMPC_STAMP(6)
   }
   if (valid) { sm.xs[j][0][c] = xo[0]; sm.xs[j][1][c] = xo[1]; }   // for the state roll-out below
 
@@ -1098,30 +1138,9 @@ solve_kernel(const DevParams P, const int B,
     }
   }
   if (states) {
-    // wrench of the final x, then X_i = s_i + Gam_t b
+    // wrench of the final x (exact: rebuilt at the last stopping test), then X_i = s_i + Gam_t b
     __syncthreads();
-    if (valid) {
-      RT xblk[2][6];
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) xblk[f][b] = sm.xs[j][f][b];
-      RT val;
-      if (c < 3) {
-        RT t0[3], t1[3];
-        const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
-        const RT r1[3] = {sm.rr[j][1][0], sm.rr[j][1][1], sm.rr[j][1][2]};
-        cross3(r0, &xblk[0][0], t0);
-        cross3(r1, &xblk[1][0], t1);
-        RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
-                    t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
-        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
-      } else {
-        RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
-        val = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
-      }
-      sm.u.itv.bw[l] = val;
-    }
+    if (valid) sm.u.itv.bwT[c][j] = bwl;
     __syncthreads();
     if (valid) {
       float* so = states + ((size_t)inst * H + j) * 13;
@@ -1132,7 +1151,7 @@ solve_kernel(const DevParams P, const int B,
         RT e = sm.s0[i][a], w = sm.s0[i][6 + a];
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
-          const RT t3[3] = {sm.u.itv.bw[6 * j2], sm.u.itv.bw[6 * j2 + 1], sm.u.itv.bw[6 * j2 + 2]};
+          const RT t3[3] = {sm.u.itv.bwT[0][j2], sm.u.itv.bwT[1][j2], sm.u.itv.bwT[2][j2]};
           if (j2 < i) {
             const float* m1 = sm.Me[pair_index(i, j2)];
             e += (RT)m1[3 * a] * t3[0] + (RT)m1[3 * a + 1] * t3[1] + (RT)m1[3 * a + 2] * t3[2];
@@ -1147,7 +1166,7 @@ solve_kernel(const DevParams P, const int B,
         const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
-          const RT fa = sm.u.itv.bw[6 * j2 + 3 + a];
+          const RT fa = sm.u.itv.bwT[3 + a][j2];
           p += kp * (RT)(i - j2) * fa;
           v += kvv * fa;
         }
@@ -1158,8 +1177,10 @@ solve_kernel(const DevParams P, const int B,
     }
   }
   if (dbg.prof && l == 0) {
-    long long* pr = dbg.prof + (size_t)inst * 8;
+    long long* pr = dbg.prof + (size_t)inst * 16;
     pr[0] = t_setup; pr[1] = t_blocks; pr[2] = t_sweep; pr[3] = clock64() - t_start; pr[4] = it; pr[5] = nfac;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pr[8 + k] = t_ph[k];
   }
   if (l == 0) {
     if (iters_out) iters_out[inst] = it;

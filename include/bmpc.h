@@ -166,9 +166,10 @@ int bmpc_low_level_control_device(bmpc_handle h, int B, const float* x_fb, const
                                   const float* q, const float* qd, const uint8_t* contact0, const float* u0,
                                   float* tau, void* stream);
 
-/* Diagnostics: when device_buf (DEVICE pointer, [max_batch][8] int64) is non-NULL every later solve
+/* Diagnostics: when device_buf (DEVICE pointer, [max_batch][16] int64) is non-NULL every later solve
  * writes per-instance shader-clock stamps {setup, block algebra, dense sweeps, total, iters,
- * factorisations, -, -}; NULL switches it off (default).  Costs a few s_memtime per phase. */
+ * factorisations, -, -, iteration phases P0..P5, stop test + adaptation, -}; NULL switches it off
+ * (default).  Costs a few s_memtime per phase. */
 int bmpc_debug_set_profile(bmpc_handle h, long long* device_buf);
 
 /* Time of the last bmpc_solve_batch* kernel launch on the handle's stream, measured with HIP

@@ -8,7 +8,7 @@ h=10
 s=bm.BatchSolver(max_batch=B)
 x,f,c,p=synth(B,h,1)
 dev=torch.device('cuda',0)
-prof=torch.zeros((B,8),dtype=torch.int64,device=dev)
+prof=torch.zeros((B,16),dtype=torch.int64,device=dev)
 _lib.check(s._lib.bmpc_debug_set_profile(s._h, prof.data_ptr()))
 tx,tf,tc,tp=[torch.from_numpy(a).to(dev) for a in (x,f,c,p)]
 st=torch.cuda.Stream()
@@ -23,3 +23,4 @@ print('B',B,'kernel ms',e0.elapsed_time(e1))
 print('cycles mean: setup %.0f blocks %.0f sweeps %.0f total %.0f | iters %.1f nfac %.2f'%tuple(pr[:,:6].mean(0)))
 it=pr[:,3]-pr[:,0]-pr[:,1]-pr[:,2]
 print('iteration cycles per iter %.0f ; blocks per factor %.0f ; sweep per factor %.0f'%((it/pr[:,4]).mean(),(pr[:,1]/pr[:,5]).mean(),(pr[:,2]/pr[:,5]).mean()))
+print('iteration phases, cycles per iteration: ' + ' '.join('%s %.0f'%(n,v) for n,v in zip(['P0','P1','P2','P3','P4','P5','tail'], (pr[:,8:15]/pr[:,4:5]).mean(0))))
