@@ -930,10 +930,14 @@ solve_kernel(const DevParams P, const int B,
     }
     __syncthreads();
     BMPC_STAMP(0)
+    // Constants a phase needs (rows of GuT, L, Kn, ...) are fetched BEFORE the barrier that precedes it:
+    // the compiler may not move LDS reads across a barrier, and with one wave per SIMD nothing else hides
+    // their latency.
     // --- P1: wrench-space gradient gb = Gt b + qt
+    RT gut[6], rfd[2][3];
     if (valid) {
-      static_assert(H % 2 == 0, "P1 reads the wrench in groups of 6");
       // 3 H doubles of the lane's component group, 3 independent accumulation chains
+      static_assert(H % 2 == 0, "P1 reads the wrench in groups of 6");
       const RT* bsrc = &sm.u.itv.bwT[c < 3 ? 0 : 3][0];
       RT g0 = qt, g1 = 0, g2 = 0;
 #pragma unroll
@@ -946,16 +950,22 @@ solve_kernel(const DevParams P, const int B,
       }
       const RT g = g0 + (g1 + g2);
       sm.u.itv.gb[l] = g;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rfd[f][a] = sm.rr[j][f][a];
     }
     __syncthreads();
     BMPC_STAMP(1)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
+    float lcol[2][6];
     if (valid) {
-      RT gut[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
-      RT gt3[3] = {sm.u.itv.gb[6 * j], sm.u.itv.gb[6 * j + 1], sm.u.itv.gb[6 * j + 2]};
-      RT gf3[3] = {sm.u.itv.gb[6 * j + 3], sm.u.itv.gb[6 * j + 4], sm.u.itv.gb[6 * j + 5]};
+      const RT gt3[3] = {sm.u.itv.gb[6 * j], sm.u.itv.gb[6 * j + 1], sm.u.itv.gb[6 * j + 2]};
+      const RT gf3[3] = {sm.u.itv.gb[6 * j + 3], sm.u.itv.gb[6 * j + 4], sm.u.itv.gb[6 * j + 5]};
+      const RT gtc = mk3[0] * gt3[0] + mk3[1] * gt3[1] + mk3[2] * gt3[2];
+      const RT gfc = mk3[0] * gf3[0] + mk3[1] * gf3[1] + mk3[2] * gf3[2];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         RT r = R2v[f] * xo[f] + wb[f];
@@ -965,17 +975,17 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
         r += cmu[f] * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
-        RT wt;
-        if (c < 3) {
-          const RT rfd[3] = {sm.rr[j][f][0], sm.rr[j][f][1], sm.rr[j][f][2]};
-          RT cr3[3];
-          cross3(gt3, rfd, cr3);               // [r]x' g_tau = g_tau x r
-          wt = mk3[0] * (cr3[0] + gf3[0]) + mk3[1] * (cr3[1] + gf3[1]) + mk3[2] * (cr3[2] + gf3[2]);
-        } else {
-          wt = mk3[0] * gt3[0] + mk3[1] * gt3[1] + mk3[2] * gt3[2];
-        }
+        // W_f' g: force variables get g_tau x r_f + g_F, moment variables get g_tau (same code for all lanes)
+        RT cr3[3];
+        cross3(gt3, rfd[f], cr3);
+        const RT wf = mk3[0] * cr3[0] + mk3[1] * cr3[1] + mk3[2] * cr3[2] + gfc;
+        const RT wt = c < 3 ? wf : gtc;
         sm.u.itv.r32[j][f][c] = (float)(r + wt);
       }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) lcol[f][i] = sm.L[j][f][i][c];
     }
     __syncthreads();
     BMPC_STAMP(2)
@@ -988,7 +998,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           rj[f][i] = sm.u.itv.r32[j][f][i];
-          s = fmaf(sm.L[j][f][i][c], rj[f][i], s);
+          s = fmaf(lcol[f][i], rj[f][i], s);
         }
       sm.u.itv.beta[l] = s;
     }
@@ -996,6 +1006,7 @@ solve_kernel(const DevParams P, const int B,
     BMPC_STAMP(3)
     // --- P4: gamma = V beta   (Vr holds -V)
     float gown = 0.f;
+    float kn[2][6], gk[2][6], lr[2][6], glr[2][6];     // rows c of Kn, GK, L, GL for P5
     if (valid) {
       f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
@@ -1006,6 +1017,15 @@ solve_kernel(const DevParams P, const int B,
       }
       gown = -((a0.x + a0.y) + (a1.x + a1.y));
       sm.u.itv.gam[l] = gown;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          kn[f][i] = sm.Kn[j][f][c][i];
+          gk[f][i] = sm.GK[j][f][c][i];
+          lr[f][i] = sm.L[j][f][c][i];
+          glr[f][i] = sm.GL[j][f][c][i];
+        }
     }
     __syncthreads();
     BMPC_STAMP(4)
@@ -1032,14 +1052,14 @@ solve_kernel(const DevParams P, const int B,
         float s = 0.f, sg = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          s = fmaf(sm.Kn[j][f][c][i], tn[i], s);
-          sg = fmaf(sm.GK[j][f][c][i], tn[i], sg);
+          s = fmaf(kn[f][i], tn[i], s);
+          sg = fmaf(gk[f][i], tn[i], sg);
         }
         if (f == 1) { s = -s; sg = -sg; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          s = fmaf(sm.L[j][f][c][i], gm[i], s);
-          sg = fmaf(sm.GL[j][f][c][i], gm[i], sg);
+          s = fmaf(lr[f][i], gm[i], s);
+          sg = fmaf(glr[f][i], gm[i], sg);
         }
         const RT xto = xo[f] - (RT)s;
         const RT ztg = axg[f] - (RT)sg;
