@@ -52,12 +52,12 @@ class Params:
         self.rho_lo = 3e-4
         self.rho_hi_f = 1.0
         self.rho_hi_m = 100.0
-        self.adapt_start = 20
+        self.adapt_start = 10
         self.adapt_every = 10
         self.adapt_growth = 1.0
         self.use_fraction = False
         self.blocks_hi = True
-        self.kappa = 10.0
+        self.kappa = 20.0
         self.alpha = 1.6
         self.max_iter = 400
         self.check_every = 5
