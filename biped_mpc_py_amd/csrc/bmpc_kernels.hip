@@ -86,9 +86,10 @@ struct Dims {
 // brings h = 10 under 20 KB: eight workgroups per CU.
 template <int H, typename RT>
 struct FacScratch {
-  double M0[H][6][6];        // D0 -> D0^-1 -> F
-  double M1[H][6][6];        // D1 -> D1^-1 -> Ka^-1
-  double ex[H][3][6];        // pivot-column exchange for the cooperative 6x6 sweeps
+  double M0[H][6][6];        // D0 -> Ka^-1 D0 W_0^-1
+  double M1[H][6][6];        // D1 -> Ka^-1
+  double M2[H][6][6];        // B = T' D1 T -> L_0
+  double ex[H][1][6];        // pivot-column exchange for the cooperative 6x6 sweep
 };
 template <int H, typename RT>
 struct IterScratch {
@@ -561,7 +562,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int a = 0; a < 3; ++a) rf[f][a] = (float)sm.rr[j][f][a];
     }
-    double m3[3][6];                           // rows of D0, D1, Ka -> their inverses
+    double m3[2][6];                           // rows of D0, D1
     double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
     {
       const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
@@ -606,7 +607,14 @@ solve_kernel(const DevParams P, const int B,
       }
     }
     __syncthreads();
-    if (valid) {                               // Ka = D0 + T' D1 T, row c
+    // One 6x6 inverse per step instead of four.  With Y = [W_0^-1; 0] (so W Y = I) and P the D-orthogonal
+    // projector I - N Ka^-1 N' D:   L = D^-1 W' F = P Y,   F = (W D^-1 W')^-1 = Y' D L.  In blocks, with
+    // B = T' D1 T (Ka = D0 + B) and I - Ka^-1 D0 = Ka^-1 B (no cancellation):
+    //   L_0 = Ka^-1 B W_0^-1,   L_1 = T Ka^-1 D0 W_0^-1,   F = (W_0^-T D0) L_0,
+    // W_0^-1 = [[0, I], [I, -[r_0]x]].
+    double brow[6], urow[6];                    // rows c of B and of U = W_0^-T D0
+    double ka[1][6];                            // row c of Ka -> Ka^-1
+    if (valid) {
       double yq[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
@@ -617,98 +625,102 @@ solve_kernel(const DevParams P, const int B,
       }
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        double s = m3[0][b];
+        double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 6; ++q) s = fma(yq[q], Tm[q][b], s);
-        m3[2][b] = s;
+        brow[b] = s;
+        ka[0][b] = m3[0][b] + s;
       }
-    }
-    __syncthreads();                           // M1 reads done before it is overwritten
-    sweep6<H, RT, 3>(m3, sm, valid, j, c);     // -> D0^-1, D1^-1, Ka^-1
-    if (valid) {
+      // U = W_0^-T D0 = [[0, I], [I, [r_0]x]] D0: rows 0..2 are rows 3..5 of D0, row 3+a is row a + ([r_0]x D0[3:6])_a
+      double wti[6];                            // row c of W_0^-T
+      {
+        const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
+        double Wt[6][6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { sm.u.fac.M0[j][c][b] = m3[0][b]; sm.u.fac.M1[j][c][b] = m3[1][b]; }
-    }
-    __syncthreads();
-    // E = sum_f W_f D_f^-1 W_f',  W_f = [[r_f]x, I; I, 0]
-    double e1[1][6];
-    double Wm[2][6][6];
+        for (int p = 0; p < 6; ++p)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+          for (int q = 0; q < 6; ++q) Wt[p][q] = 0.0;
 #pragma unroll
-      for (int p = 0; p < 6; ++p)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Wm[f][p][q] = 0.0;
-      Wm[f][0][1] = -rf[f][2]; Wm[f][0][2] = rf[f][1];
-      Wm[f][1][0] = rf[f][2];  Wm[f][1][2] = -rf[f][0];
-      Wm[f][2][0] = -rf[f][1]; Wm[f][2][1] = rf[f][0];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { Wm[f][a][3 + a] = 1.0; Wm[f][3 + a][a] = 1.0; }
-    }
-    double Wrow[2][6];                         // W_f[c, :]
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        double a1 = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) a1 = fma(mkd[cc], Wm[f][cc][p], a1);
-        Wrow[f][p] = a1;
-      }
-    if (valid) {
-#pragma unroll
-      for (int b = 0; b < 6; ++b) e1[0][b] = 0.0;
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        double yq[6];
+        for (int a = 0; a < 3; ++a) { Wt[a][3 + a] = 1.0; Wt[3 + a][a] = 1.0; }
+        Wt[3][4] = -r0[2]; Wt[3][5] = r0[1];
+        Wt[4][3] = r0[2];  Wt[4][5] = -r0[0];
+        Wt[5][3] = -r0[1]; Wt[5][4] = r0[0];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          double s = 0.0;
+          double a1 = 0.0;
 #pragma unroll
-          for (int p = 0; p < 6; ++p) s = fma(Wrow[f][p], (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][p][q], s);
-          yq[q] = s;
+          for (int cc = 0; cc < 6; ++cc) a1 = fma(mkd[cc], Wt[cc][q], a1);
+          wti[q] = a1;
         }
-#pragma unroll
-        for (int b = 0; b < 6; ++b)
-#pragma unroll
-          for (int q = 0; q < 6; ++q) e1[0][b] = fma(yq[q], Wm[f][b][q], e1[0][b]);
       }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s = fma(wti[q], sm.u.fac.M0[j][q][b], s);
+        urow[b] = s;
+      }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
-    __syncthreads();                           // M0, M1 (D_f^-1) reads done: the slots now receive F and Ka^-1
-    sweep6<H, RT, 1>(e1, sm, valid, j, c);     // -> F = E^-1
+    sweep6<H, RT, 1>(ka, sm, valid, j, c);      // -> Ka^-1 (barriers inside: the M1 reads above are done)
     if (valid) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { sm.u.fac.M0[j][c][b] = e1[0][b]; sm.u.fac.M1[j][c][b] = m3[2][b]; }
+      for (int b = 0; b < 6; ++b) sm.u.fac.M1[j][c][b] = ka[0][b];
+    }
+    double x1[6], x0[6];                        // rows c of Ka^-1 B and Ka^-1 D0
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double s1 = 0.0, s0 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          s1 = fma(ka[0][q], sm.u.fac.M2[j][q][b], s1);
+          s0 = fma(ka[0][q], sm.u.fac.M0[j][q][b], s0);
+        }
+        x1[b] = s1; x0[b] = s0;
+      }
+    }
+    __syncthreads();                            // B, D0 consumed; Ka^-1 published
+    double fv64[6];                             // row c of F
+    if (valid) {
+      const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
+      // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0]
+      double l0[6], y0[6];
+      {
+        double cr[3];
+        const double q1[3] = {x1[3], x1[4], x1[5]};
+        cross3(q1, r0, cr);
+        l0[0] = x1[3]; l0[1] = x1[4]; l0[2] = x1[5];
+        l0[3] = x1[0] - cr[0]; l0[4] = x1[1] - cr[1]; l0[5] = x1[2] - cr[2];
+        const double q0[3] = {x0[3], x0[4], x0[5]};
+        cross3(q0, r0, cr);
+        y0[0] = x0[3]; y0[1] = x0[4]; y0[2] = x0[5];
+        y0[3] = x0[0] - cr[0]; y0[4] = x0[1] - cr[1]; y0[5] = x0[2] - cr[2];
+      }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        sm.L[j][0][c][b] = (float)l0[b];
+        sm.u.fac.M2[j][c][b] = l0[b];           // L_0 rows for F
+        sm.u.fac.M0[j][c][b] = y0[b];           // Ka^-1 D0 W_0^-1 rows for L_1
+      }
     }
     __syncthreads();
     if (valid) {
-      // L_f = D_f^-1 W_f' F, row c (variable c of foot f)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        double xq[6];                          // (D_f^-1 W_f')[c][p] = sum_q Dinv[c][q] W[p][q]
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-          double s = 0.0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) s = fma(m3[f][q], Wm[f][p][q], s);
-          xq[p] = s;
-        }
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          double s = 0.0;
-#pragma unroll
-          for (int p = 0; p < 6; ++p) s = fma(xq[p], sm.u.fac.M0[j][p][b], s);
-          sm.L[j][f][c][b] = (float)s;
-        }
-      }
-      // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        double s2 = 0.0;
+        double sl = 0.0, sf = 0.0, sk = 0.0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s2 = fma(Trow[q], sm.u.fac.M1[j][q][b], s2);
-        sm.Kn[j][0][c][b] = (float)m3[2][b];
-        sm.Kn[j][1][c][b] = (float)s2;
+        for (int q = 0; q < 6; ++q) {
+          sl = fma(Trow[q], sm.u.fac.M0[j][q][b], sl);   // L_1 = T (Ka^-1 D0 W_0^-1)
+          sf = fma(urow[q], sm.u.fac.M2[j][q][b], sf);   // F = U L_0
+          sk = fma(Trow[q], sm.u.fac.M1[j][q][b], sk);   // T Ka^-1
+        }
+        sm.L[j][1][c][b] = (float)sl;
+        fv64[b] = sf;
+        // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
+        sm.Kn[j][0][c][b] = (float)ka[0][b];
+        sm.Kn[j][1][c][b] = (float)sk;
       }
     }
     __syncthreads();
@@ -753,7 +765,7 @@ solve_kernel(const DevParams P, const int B,
       }
       float fv[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) fv[b] = (float)sm.u.fac.M0[j][c][b];
+      for (int b = 0; b < 6; ++b) fv[b] = (float)fv64[b];
 #pragma unroll
       for (int j2 = 0; j2 < H; ++j2) {
         const float mj = (j2 == j) ? 1.f : 0.f;
