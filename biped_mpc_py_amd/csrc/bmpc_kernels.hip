@@ -134,6 +134,17 @@ struct alignas(16) Smem {
 
 __device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
 
+// Workgroup synchronisation point.  A one-wave workgroup needs no hardware barrier and no wait: the
+// LDS executes a wave's instructions in issue order, so a ds_write is complete for all 64 lanes
+// before the wave's next ds_read starts.  What remains is a compiler-level fence that keeps LDS
+// accesses on their side of the point (the s_waitcnt lgkmcnt(0) that __syncthreads() would add costs
+// a full LDS round trip per exchange, ~10 % of the kernel).  Larger workgroups take the real barrier.
+template <int NT>
+__device__ __forceinline__ void wg_sync() {
+  if constexpr (NT == 64) asm volatile("" ::: "memory");
+  else __syncthreads();
+}
+
 // max over the workgroup of 4 NON-NEGATIVE floats (or NaN) at once.  The order of such floats is
 // the order of their bit patterns, with NaN above everything, so the reduction is an unsigned max:
 // six DPP steps per value inside a wave (shifts read 0 = the neutral element where a source lane does
@@ -159,7 +170,7 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[q][w] = v[q];
     }
-    __syncthreads();
+    wg_sync<NT>();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       unsigned m = __float_as_uint(red[q][0]);
@@ -167,7 +178,7 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
       for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
       v[q] = __uint_as_float(m);
     }
-    __syncthreads();
+    wg_sync<NT>();
   }
 }
 
@@ -175,13 +186,14 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
 // On exit the rows hold the INVERSES.  All threads of the workgroup must call (barriers inside).
 template <int H, typename RT, int NM>
 __device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool valid, int j, int c) {
+  constexpr int NT = Dims<H>::NT;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     if (valid) {
 #pragma unroll
       for (int q = 0; q < NM; ++q) sm.u.fac.ex[j][q][c] = m[q][k];
     }
-    __syncthreads();
+    wg_sync<NT>();
     if (valid) {
 #pragma unroll
       for (int q = 0; q < NM; ++q) {
@@ -199,7 +211,7 @@ __device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool
         m[q][k] = t;            // pivot lane: -1/p ; others: a_ik / p
       }
     }
-    __syncthreads();
+    wg_sync<NT>();
   }
   // swept matrix = -A^-1
 #pragma unroll
@@ -347,7 +359,7 @@ solve_kernel(const DevParams P, const int B,
         for (int a = 0; a < 3; ++a) sm.rr[j][f][a] = fr[3 * f + a] - xr[3 + a];           // REF:174-175
     }
   }
-  __syncthreads();
+  wg_sync<NT>();
 #pragma unroll
   for (int q = 0; q < 9; ++q) Pj[q] = 0;
 #pragma unroll 1
@@ -376,7 +388,7 @@ solve_kernel(const DevParams P, const int B,
       for (int i = 0; i < 12; ++i) { sm.u.itv.err[j][i] = e12[i] - xr[i]; sm.s0[j][i] = e12[i]; }
     }
   }
-  __syncthreads();
+  wg_sync<NT>();
   // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2: one (i, j2) pair per lane and pass
   for (int idx = l; idx < Dims<H>::NPAIR; idx += NT) {
     int i = (int)((1.f + sqrtf(1.f + 8.f * (float)idx)) * 0.5f);     // invert idx = i (i - 1) / 2 + j2
@@ -393,7 +405,7 @@ solve_kernel(const DevParams P, const int B,
         sm.Me[idx][3 * a + b] = (float)(dt * dt * s);
       }
   }
-  __syncthreads();
+  wg_sync<NT>();
 
   // ------------------------------------------------------------------ B. wrench-space Hessian row
   // Row of Gt against one component group of the wrench (torque lanes: tau, force lanes: F), laid out
@@ -543,7 +555,7 @@ solve_kernel(const DevParams P, const int B,
       sm.rvg[j][0][c] = (float)rvg[0];
       sm.rvg[j][1][c] = (float)rvg[1];
     }
-    __syncthreads();
+    wg_sync<NT>();
     // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so
     // that none of it is live (= holds registers) during the iterations
     int co = c;
@@ -606,7 +618,7 @@ solve_kernel(const DevParams P, const int B,
         for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[f][b];
       }
     }
-    __syncthreads();
+    wg_sync<NT>();
     // One 6x6 inverse per step instead of four.  With Y = [W_0^-1; 0] (so W Y = I) and P the D-orthogonal
     // projector I - N Ka^-1 N' D:   L = D^-1 W' F = P Y,   F = (W D^-1 W')^-1 = Y' D L.  In blocks, with
     // B = T' D1 T (Ka = D0 + B) and I - Ka^-1 D0 = Ka^-1 B (no cancellation):
@@ -681,7 +693,7 @@ solve_kernel(const DevParams P, const int B,
         x1[b] = s1; x0[b] = s0;
       }
     }
-    __syncthreads();                            // B, D0 consumed; Ka^-1 published
+    wg_sync<NT>();                            // B, D0 consumed; Ka^-1 published
     double fv64[6];                             // row c of F
     if (valid) {
       const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
@@ -705,7 +717,7 @@ solve_kernel(const DevParams P, const int B,
         sm.u.fac.M0[j][c][b] = y0[b];           // Ka^-1 D0 W_0^-1 rows for L_1
       }
     }
-    __syncthreads();
+    wg_sync<NT>();
     if (valid) {
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
@@ -723,7 +735,7 @@ solve_kernel(const DevParams P, const int B,
         sm.Kn[j][1][c][b] = (float)sk;
       }
     }
-    __syncthreads();
+    wg_sync<NT>();
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
@@ -787,7 +799,7 @@ solve_kernel(const DevParams P, const int B,
           pos += (pos < 0) ? NW : 0;
           buf[pos] = VROW(u);
         }
-        __syncthreads();
+        wg_sync<NT>();
         if (valid) {
           // fetch the pivot vector first (back-to-back ds_read_b128, one wait), then compute: with one
           // wave per SIMD nothing else hides the LDS latency.  (Chunked fetch costs less registers.)
@@ -862,7 +874,7 @@ solve_kernel(const DevParams P, const int B,
   // exact axg, bwl from x (exchange through LDS); all threads call
   auto refresh = [&]() {
     if (valid) { sm.xs[j][0][c] = xo[0]; sm.xs[j][1][c] = xo[1]; }
-    __syncthreads();
+    wg_sync<NT>();
     if (valid) {
       RT xblk[2][6], gu[6];
 #pragma unroll
@@ -940,7 +952,7 @@ solve_kernel(const DevParams P, const int B,
       }
       sm.u.itv.bwT[c][j] = bwl;
     }
-    __syncthreads();
+    wg_sync<NT>();
     BMPC_STAMP(0)
     // Constants a phase needs (rows of GuT, L, Kn, ...) are fetched BEFORE the barrier that precedes it:
     // the compiler may not move LDS reads across a barrier, and with one wave per SIMD nothing else hides
@@ -969,7 +981,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int a = 0; a < 3; ++a) rfd[f][a] = sm.rr[j][f][a];
     }
-    __syncthreads();
+    wg_sync<NT>();
     BMPC_STAMP(1)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     float lcol[2][6];
@@ -999,7 +1011,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int i = 0; i < 6; ++i) lcol[f][i] = sm.L[j][f][i][c];
     }
-    __syncthreads();
+    wg_sync<NT>();
     BMPC_STAMP(2)
     // --- P3: beta = L' r
     float rj[2][6];
@@ -1014,7 +1026,7 @@ solve_kernel(const DevParams P, const int B,
         }
       sm.u.itv.beta[l] = s;
     }
-    __syncthreads();
+    wg_sync<NT>();
     BMPC_STAMP(3)
     // --- P4: gamma = V beta   (Vr holds -V)
     float gown = 0.f;
@@ -1039,7 +1051,7 @@ solve_kernel(const DevParams P, const int B,
           glr[f][i] = sm.GL[j][f][c][i];
         }
     }
-    __syncthreads();
+    wg_sync<NT>();
     BMPC_STAMP(4)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
@@ -1171,9 +1183,9 @@ solve_kernel(const DevParams P, const int B,
   }
   if (states) {
     // wrench of the final x (exact: rebuilt at the last stopping test), then X_i = s_i + Gam_t b
-    __syncthreads();
+    wg_sync<NT>();
     if (valid) sm.u.itv.bwT[c][j] = bwl;
-    __syncthreads();
+    wg_sync<NT>();
     if (valid) {
       float* so = states + ((size_t)inst * H + j) * 13;
       const int i = j;
