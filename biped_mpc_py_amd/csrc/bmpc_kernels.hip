@@ -954,9 +954,6 @@ solve_kernel(const DevParams P, const int B,
     }
     wg_sync<NT>();
     BMPC_STAMP(0)
-    // Constants a phase needs (rows of GuT, L, Kn, ...) are fetched BEFORE the barrier that precedes it:
-    // the compiler may not move LDS reads across a barrier, and with one wave per SIMD nothing else hides
-    // their latency.
     // --- P1: wrench-space gradient gb = Gt b + qt
     RT gut[6], rfd[2][3];
     if (valid) {
@@ -974,18 +971,18 @@ solve_kernel(const DevParams P, const int B,
       }
       const RT g = g0 + (g1 + g2);
       sm.u.itv.gb[l] = g;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) rfd[f][a] = sm.rr[j][f][a];
     }
     wg_sync<NT>();
     BMPC_STAMP(1)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     float lcol[2][6];
     if (valid) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rfd[f][a] = sm.rr[j][f][a];
       const RT gt3[3] = {sm.u.itv.gb[6 * j], sm.u.itv.gb[6 * j + 1], sm.u.itv.gb[6 * j + 2]};
       const RT gf3[3] = {sm.u.itv.gb[6 * j + 3], sm.u.itv.gb[6 * j + 4], sm.u.itv.gb[6 * j + 5]};
       const RT gtc = mk3[0] * gt3[0] + mk3[1] * gt3[1] + mk3[2] * gt3[2];
@@ -1041,15 +1038,6 @@ solve_kernel(const DevParams P, const int B,
       }
       gown = -((a0.x + a0.y) + (a1.x + a1.y));
       sm.u.itv.gam[l] = gown;
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          kn[f][i] = sm.Kn[j][f][c][i];
-          gk[f][i] = sm.GK[j][f][c][i];
-          lr[f][i] = sm.L[j][f][c][i];
-          glr[f][i] = sm.GL[j][f][c][i];
-        }
     }
     wg_sync<NT>();
     BMPC_STAMP(4)
@@ -1060,6 +1048,15 @@ solve_kernel(const DevParams P, const int B,
       float gm[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) gm[i] = sm.u.itv.gam[6 * j + i];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          kn[f][i] = sm.Kn[j][f][c][i];
+          gk[f][i] = sm.GK[j][f][c][i];
+          lr[f][i] = sm.L[j][f][c][i];
+          glr[f][i] = sm.GL[j][f][c][i];
+        }
       // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
       float tn[6];
       {
