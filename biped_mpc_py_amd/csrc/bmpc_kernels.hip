@@ -122,6 +122,7 @@ struct alignas(16) Smem {
   // step data
   RT Iw[H][9];               // world inverse inertia
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
+  alignas(16) RT rx[H][2][6][2];  // per variable: {r_f[a+2], r_f[a+1]} (cyclic) for force variable a, zeros for moments
   RT s0[H][12];              // free response (X with u = 0)
   float Me[Dims<H>::NPAIR > 0 ? Dims<H>::NPAIR : 1][9];   // dt^2 (P_i - P_j) Iw_j, i > j (data: f32)
   float rvg[H][2][6];
@@ -529,6 +530,15 @@ solve_kernel(const DevParams P, const int B,
     }
 #pragma unroll
     for (int a2 = 0; a2 < 3; ++a2) drf[a2] = (float)sm.rr[j][0][a2] - (float)sm.rr[j][1][a2];
+    if (valid) {
+      const int a3 = c < 3 ? c : c - 3;
+      const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        sm.rx[j][f][c][0] = c < 3 ? sm.rr[j][f][i2] : (RT)0;
+        sm.rx[j][f][c][1] = c < 3 ? sm.rr[j][f][i1] : (RT)0;
+      }
+    }
   }
 
   // ------------------------------------------------------------------ D. factor: L, Na, V for penalties rv
@@ -955,7 +965,6 @@ solve_kernel(const DevParams P, const int B,
     wg_sync<NT>();
     BMPC_STAMP(0)
     // --- P1: wrench-space gradient gb = Gt b + qt
-    RT gut[6], rfd[2][3];
     if (valid) {
       // 3 H doubles of the lane's component group, 3 independent accumulation chains
       static_assert(H % 2 == 0, "P1 reads the wrench in groups of 6");
@@ -977,16 +986,16 @@ solve_kernel(const DevParams P, const int B,
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     float lcol[2][6];
     if (valid) {
+      RT gut[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) rfd[f][a] = sm.rr[j][f][a];
-      const RT gt3[3] = {sm.u.itv.gb[6 * j], sm.u.itv.gb[6 * j + 1], sm.u.itv.gb[6 * j + 2]};
-      const RT gf3[3] = {sm.u.itv.gb[6 * j + 3], sm.u.itv.gb[6 * j + 4], sm.u.itv.gb[6 * j + 5]};
-      const RT gtc = mk3[0] * gt3[0] + mk3[1] * gt3[1] + mk3[2] * gt3[2];
-      const RT gfc = mk3[0] * gf3[0] + mk3[1] * gf3[1] + mk3[2] * gf3[2];
+      // W_f' g for this lane's variable: force variable a gets (g_tau x r_f)_a + g_F[a], moment variable a gets
+      // g_tau[a].  One straight line for all lanes: the cyclic neighbours of a are picked by address, the lever
+      // arm components come from a per-lane table that is zero for moment variables.
+      const int a3 = c < 3 ? c : c - 3;
+      const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
+      const RT g1 = sm.u.itv.gb[6 * j + i1], g2 = sm.u.itv.gb[6 * j + i2];
+      const RT gsel = sm.u.itv.gb[6 * j + (c < 3 ? c + 3 : c - 3)];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         RT r = R2v[f] * xo[f] + wb[f];
@@ -996,11 +1005,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
         r += cmu[f] * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
-        // W_f' g: force variables get g_tau x r_f + g_F, moment variables get g_tau (same code for all lanes)
-        RT cr3[3];
-        cross3(gt3, rfd[f], cr3);
-        const RT wf = mk3[0] * cr3[0] + mk3[1] * cr3[1] + mk3[2] * cr3[2] + gfc;
-        const RT wt = c < 3 ? wf : gtc;
+        const RT wt = g1 * sm.rx[j][f][c][0] - g2 * sm.rx[j][f][c][1] + gsel;
         sm.u.itv.r32[j][f][c] = (float)(r + wt);
       }
 #pragma unroll
