@@ -85,7 +85,7 @@ struct Dims {
 // vectors (+ the set-up-only step data) are never live at the same time and share one region, which
 // brings h = 10 under 20 KB: eight workgroups per CU.
 template <int H, typename RT>
-struct FacScratch {
+struct alignas(16) FacScratch {
   double M0[H][6][6];        // D0 -> Ka^-1 D0 W_0^-1
   double M1[H][6][6];        // D1 -> Ka^-1
   double M2[H][6][6];        // B = T' D1 T -> L_0
@@ -183,6 +183,22 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
   }
 }
 
+// out[b] += sum_q w[q] * M[q][b] for a 6x6 f64 matrix in LDS: whole rows are fetched (three 16-byte
+// reads each) and the six outputs accumulate as independent chains.
+__device__ __forceinline__ void row_times_mat6(const double (&w)[6], const double (*M)[6], double (&out)[6]) {
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    double row[6];
+#pragma unroll
+    for (int b = 0; b < 6; b += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(&M[q][b]);
+      row[b] = v.x; row[b + 1] = v.y;
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) out[b] = fma(w[q], row[b], out[b]);
+  }
+}
+
 // Cooperative symmetric sweep of NM 6x6 SPD matrices per step: lane (j, c) holds row c of each.
 // On exit the rows hold the INVERSES.  All threads of the workgroup must call (barriers inside).
 template <int H, typename RT, int NM>
@@ -201,7 +217,10 @@ __device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool
         double col[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) col[b] = sm.u.fac.ex[j][q][b];
-        const double pinv = 1.0 / col[k];
+        // reciprocal by v_rcp_f64 + two Newton steps (a correctly rounded IEEE division is ~40 dependent instructions)
+        double pinv = __builtin_amdgcn_rcp(col[k]);
+        pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
+        pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
         const bool isp = (c == k);
         const double t = isp ? -pinv : m[q][k] * pinv;
 #pragma unroll
@@ -570,10 +589,9 @@ solve_kernel(const DevParams P, const int B,
     // that none of it is live (= holds registers) during the iterations
     int co = c;
     asm volatile("" : "+v"(co));
-    float mkf[6];
     double mkd[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { mkf[k] = (co == k) ? 1.f : 0.f; mkd[k] = (co == k) ? 1.0 : 0.0; }
+    for (int k = 0; k < 6; ++k) mkd[k] = (co == k) ? 1.0 : 0.0;
     const float lh = (float)P.lh, lt = (float)P.lt;
     float ey[3], ez[3], muf[2], rf[2][3];
 #pragma unroll
@@ -612,10 +630,9 @@ solve_kernel(const DevParams P, const int B,
         double wc[6];                          // rho_r * G[r][c]
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          float gc = 0.f;
-#pragma unroll
-          for (int b = 0; b < 6; ++b) gc = fmaf(mkf[b], G[r][b], gc);
-          wc[r] = (double)sm.rvg[j][f][r] * (double)gc;
+          // column c of G_f from the mu-free table; the friction rows' f_z entry is -mu_f
+          const double gc = (double)sm.GuT[c][r] - ((co == 2 && r < 4) ? (double)muf[f] : 0.0);
+          wc[r] = (double)sm.rvg[j][f][r] * gc;
         }
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -637,14 +654,8 @@ solve_kernel(const DevParams P, const int B,
     double brow[6], urow[6];                    // rows c of B and of U = W_0^-T D0
     double ka[1][6];                            // row c of Ka -> Ka^-1
     if (valid) {
-      double yq[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        double s = 0.0;
-#pragma unroll
-        for (int p = 0; p < 6; ++p) s = fma(Tcol[p], sm.u.fac.M1[j][p][q], s);
-        yq[q] = s;
-      }
+      double yq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      row_times_mat6(Tcol, sm.u.fac.M1[j], yq);
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
         double s = 0.0;
@@ -676,12 +687,8 @@ solve_kernel(const DevParams P, const int B,
         }
       }
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) s = fma(wti[q], sm.u.fac.M0[j][q][b], s);
-        urow[b] = s;
-      }
+      for (int b = 0; b < 6; ++b) urow[b] = 0.0;
+      row_times_mat6(wti, sm.u.fac.M0[j], urow);
 #pragma unroll
       for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
@@ -693,15 +700,9 @@ solve_kernel(const DevParams P, const int B,
     double x1[6], x0[6];                        // rows c of Ka^-1 B and Ka^-1 D0
     if (valid) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        double s1 = 0.0, s0 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          s1 = fma(ka[0][q], sm.u.fac.M2[j][q][b], s1);
-          s0 = fma(ka[0][q], sm.u.fac.M0[j][q][b], s0);
-        }
-        x1[b] = s1; x0[b] = s0;
-      }
+      for (int b = 0; b < 6; ++b) { x1[b] = 0.0; x0[b] = 0.0; }
+      row_times_mat6(ka[0], sm.u.fac.M2[j], x1);
+      row_times_mat6(ka[0], sm.u.fac.M0[j], x0);
     }
     wg_sync<NT>();                            // B, D0 consumed; Ka^-1 published
     double fv64[6];                             // row c of F
@@ -729,35 +730,27 @@ solve_kernel(const DevParams P, const int B,
     }
     wg_sync<NT>();
     if (valid) {
+      double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int b = 0; b < 6; ++b) fv64[b] = 0.0;
+      row_times_mat6(Trow, sm.u.fac.M0[j], sl);     // L_1 = T (Ka^-1 D0 W_0^-1)
+      row_times_mat6(urow, sm.u.fac.M2[j], fv64);   // F = U L_0
+      row_times_mat6(Trow, sm.u.fac.M1[j], sk);     // T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        double sl = 0.0, sf = 0.0, sk = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          sl = fma(Trow[q], sm.u.fac.M0[j][q][b], sl);   // L_1 = T (Ka^-1 D0 W_0^-1)
-          sf = fma(urow[q], sm.u.fac.M2[j][q][b], sf);   // F = U L_0
-          sk = fma(Trow[q], sm.u.fac.M1[j][q][b], sk);   // T Ka^-1
-        }
-        sm.L[j][1][c][b] = (float)sl;
-        fv64[b] = sf;
+        sm.L[j][1][c][b] = (float)sl[b];
         // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
         sm.Kn[j][0][c][b] = (float)ka[0][b];
-        sm.Kn[j][1][c][b] = (float)sk;
+        sm.Kn[j][1][c][b] = (float)sk[b];
       }
     }
     wg_sync<NT>();
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        float G[6][6], gr[6];
-        general_rows(muf[f], ey, ez, lh, lt, G);
+        float gr[6];                           // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          float g1 = 0.f;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) g1 = fmaf(mkf[r], G[r][b], g1);
-          gr[b] = g1;
-        }
+        for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[c][b] - ((b == 2 && co < 4) ? muf[f] : 0.f);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           float gk = 0.f, gl = 0.f;
