@@ -1066,6 +1066,7 @@ solve_kernel(const DevParams P, const int B,
         tn[4] = rj[0][4] - rj[1][4];
         tn[5] = rj[0][5] - rj[1][5];
       }
+      RT st_pb[2], st_pg[2], st_x[2], st_g[2], st_dx[2];     // residual statistics inputs (used at stopping tests)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         float s = 0.f, sg = 0.f;
@@ -1090,10 +1091,7 @@ solve_kernel(const DevParams P, const int B,
           const RT zn = min_rt(max_rt(cand, lb[f]), ub[f]);
           yb[f] += rvb[f] * (zr - zn);
           zb[f] = zn;
-          if (check_now) {
-            rp = fmaxf(rp, fabsf((float)(ztb - zn)));
-            nz = fmaxf(nz, fabsf((float)ztb));
-          }
+          st_pb[f] = ztb - zn;
         }
         // general row: l = -inf, u = 0
         {
@@ -1102,20 +1100,25 @@ solve_kernel(const DevParams P, const int B,
           const RT zn = min_rt(cand, (RT)0);
           yg[f] += rvg[f] * (zr - zn);
           zg[f] = zn;
-          if (check_now) {
-            rp = fmaxf(rp, fabsf((float)(ztg - zn)));
-            nz = fmaxf(nz, fabsf((float)ztg));
-          }
+          st_pg[f] = ztg - zn;
         }
-        if (check_now) {
-          rs = fmaxf(rs, fabsf((float)(xto - xo[f])));
-          // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
-          nx = (xto == xto) ? fmaxf(nx, fabsf((float)xto)) : __builtin_inff();
-        }
+        st_x[f] = xto; st_g[f] = ztg; st_dx[f] = xto - xo[f];
         xo[f] = alpha * xto + (1 - alpha) * xo[f];
         axg[f] = alpha * ztg + (1 - alpha) * axg[f];
       }
       bwl -= alpha * (RT)gown;
+      if (check_now) {
+        // a real (uniform) branch: predicated, this costs ~25 instructions in every iteration
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          rp = fmaxf(rp, fmaxf(fabsf((float)st_pb[f]), fabsf((float)st_pg[f])));
+          nz = fmaxf(nz, fmaxf(fabsf((float)st_x[f]), fabsf((float)st_g[f])));
+          rs = fmaxf(rs, fabsf((float)st_dx[f]));
+          // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
+          nx = (st_x[f] == st_x[f]) ? fmaxf(nx, fabsf((float)st_x[f])) : __builtin_inff();
+        }
+      }
     }
     ++it;
     BMPC_STAMP(5)
