@@ -436,67 +436,84 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
   for (int q = 0; q < 3 * H; ++q) Grow[q] = 0.f;
   if (valid) {
+    // The step loops run over wave-uniform ranges with per-lane predicates, so the partner blocks
+    // Me[i][j2] are broadcast reads and the (i, j2) work of one i is a batch of independent FMAs.
     if (c < 3) {
       const int a = c;
       RT nw[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) nw[q] = dt * sm.Iw[j][3 * q + a] * (RT)P.Q[6 + q];   // Q_w weighted column
+      RT acc[3 * H];                            // sum_{i > max(j, j2)} (Me_i,j Q Me_i,j2)[a][b] at b H + j2 (then the row itself)
 #pragma unroll
-      for (int j2 = 0; j2 < H; ++j2) {
-        const int mx = j > j2 ? j : j2;
-        RT acc[3] = {0, 0, 0};
+      for (int q = 0; q < 3 * H; ++q) acc[q] = 0;
+      RT s = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s += nw[q] * sm.u.itv.err[j][6 + q];             // i = j term of qt
 #pragma unroll 1
-        for (int i = mx + 1; i < H; ++i) {
-          const float* m1 = sm.Me[pair_index(i, j)];
-          const float* m2 = sm.Me[pair_index(i, j2)];
+      for (int i = 1; i < H; ++i) {             // uniform
+        const bool act = i > j;
+        const float* m1 = sm.Me[pair_index(i, act ? j : 0)];
+        RT u[3];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const RT u = (RT)m1[3 * q + a] * (RT)P.Q[q];
+        for (int q = 0; q < 3; ++q) u[q] = act ? (RT)m1[3 * q + a] * (RT)P.Q[q] : (RT)0;
 #pragma unroll
-            for (int b = 0; b < 3; ++b) acc[b] += u * (RT)m2[3 * q + b];
+        for (int q = 0; q < 3; ++q) s += u[q] * sm.u.itv.err[i][q] + (act ? nw[q] : (RT)0) * sm.u.itv.err[i][6 + q];
+#pragma unroll
+        for (int j2 = 0; j2 < H - 1; ++j2) {
+          if (j2 < i) {                         // uniform
+            const float* m2 = sm.Me[pair_index(i, j2)];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+              for (int b = 0; b < 3; ++b) acc[b * H + j2] += u[q] * (RT)m2[3 * q + b];
           }
         }
-        const RT cnt = (RT)(H - mx);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          RT s = 0;
-#pragma unroll
-          for (int q = 0; q < 3; ++q) s += nw[q] * dt * sm.Iw[j2][3 * q + b];
-          const RT gval = 2 * (acc[b] + cnt * s);
-          Grow[b * H + j2] = (float)gval;
-          if (dbg.Gt) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + b] = (double)gval;
-        }
-      }
-      RT s = 0;
-#pragma unroll 1
-      for (int i = j; i < H; ++i) {
-        if (i > j) {
-          const float* m1 = sm.Me[pair_index(i, j)];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) s += (RT)m1[3 * q + a] * (RT)P.Q[q] * sm.u.itv.err[i][q];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) s += nw[q] * sm.u.itv.err[i][6 + q];
       }
       qt = 2 * s;
+#pragma unroll
+      for (int j2 = 0; j2 < H; ++j2) {
+        const RT cnt = (RT)(H - (j > j2 ? j : j2));
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          RT sw = 0;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) sw += nw[q] * dt * sm.Iw[j2][3 * q + b];
+          const RT gval = 2 * (acc[b * H + j2] + cnt * sw);
+          Grow[b * H + j2] = (float)gval;
+          acc[b * H + j2] = gval;
+        }
+      }
+      if (dbg.Gt) {                             // fp64 view of the row (tests)
+#pragma unroll
+        for (int j2 = 0; j2 < H; ++j2)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + b] = (double)acc[b * H + j2];
+      }
     } else {
       const int a = c - 3;
       const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
+      RT gdbg[H];
 #pragma unroll
       for (int j2 = 0; j2 < H; ++j2) {
+        // sum_{i = mx}^{H-1} (i - j)(i - j2), closed form: with n terms and offsets d1, d2 (one of them 0)
         const int mx = j > j2 ? j : j2;
-        RT s2 = 0;
-#pragma unroll 1
-        for (int i = mx; i < H; ++i) s2 += (RT)((i - j) * (i - j2));
-        const RT gval = 2 * ((RT)P.Q[3 + a] * kp * kp * s2 + (RT)P.Q[9 + a] * kvv * kvv * (RT)(H - mx));
+        const int n = H - mx, d1 = mx - j, d2 = mx - j2;
+        const int s2 = n * d1 * d2 + (d1 + d2) * (n * (n - 1) / 2) + (n - 1) * n * (2 * n - 1) / 6;
+        const RT gval = 2 * ((RT)P.Q[3 + a] * kp * kp * (RT)s2 + (RT)P.Q[9 + a] * kvv * kvv * (RT)n);
 #pragma unroll
         for (int a2 = 0; a2 < 3; ++a2) Grow[a2 * H + j2] = (a2 == a) ? (float)gval : 0.f;
-        if (dbg.Gt) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + 3 + a] = (double)gval;
+        gdbg[j2] = gval;
+      }
+      if (dbg.Gt) {
+#pragma unroll
+        for (int j2 = 0; j2 < H; ++j2) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + 3 + a] = (double)gdbg[j2];
       }
       RT s = 0;
-#pragma unroll 1
-      for (int i = j; i < H; ++i)
-        s += kp * (RT)(i - j) * (RT)P.Q[3 + a] * sm.u.itv.err[i][3 + a] + kvv * (RT)P.Q[9 + a] * sm.u.itv.err[i][9 + a];
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const RT w1 = i >= j ? kp * (RT)(i - j) * (RT)P.Q[3 + a] : (RT)0, w2 = i >= j ? kvv * (RT)P.Q[9 + a] : (RT)0;
+        s += w1 * sm.u.itv.err[i][3 + a] + w2 * sm.u.itv.err[i][9 + a];
+      }
       qt = 2 * s;
     }
     if (dbg.qt) dbg.qt[(size_t)inst * NW + l] = (double)qt;
