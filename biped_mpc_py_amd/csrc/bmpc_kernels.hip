@@ -113,7 +113,7 @@ struct alignas(16) Smem {
     IterScratch<H, RT> itv;
   } u;
   RT xs[H][2][6];            // x (relaxed iterate); re-read per iteration instead of living in VGPRs
-  alignas(16) float piv[2][NW];     // sweep pivot column, double buffered
+  alignas(16) float piv[2][Dims<H>::NT];   // sweep pivot column, double buffered (slots >= NW: idle lanes)
   // block-diagonal part of K^-1
   alignas(16) float L[H][2][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
   alignas(16) float Kn[H][2][6][6];     // [0]: Ka^-1, [1]: T Ka^-1   (N Ka^-1 N' applied as N (Ka^-1 (N' r)))
@@ -810,17 +810,19 @@ solve_kernel(const DevParams P, const int B,
     constexpr int U = 6;
     static_assert(NW % U == 0 && U % 2 == 0, "sweep group must divide 6H and be even");
 #pragma unroll 1
+    // The idle lanes of the last wave run the sweep too (no exec-mask juggling per pivot): they publish
+    // into slots nobody reads and update a row nobody uses.
     for (int k0 = 0; k0 < NW; k0 += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float* buf = sm.piv[u & 1];
-        if (valid) {
+        {
           int pos = l - k0;
           pos += (pos < 0) ? NW : 0;
-          buf[pos] = VROW(u);
+          buf[valid ? pos : l] = VROW(u);
         }
         wg_sync<NT>();
-        if (valid) {
+        {
           // fetch the pivot vector first (back-to-back ds_read_b128, one wait), then compute: with one
           // wave per SIMD nothing else hides the LDS latency.  (Chunked fetch costs less registers.)
 #ifdef BMPC_PIVOT_CHUNKS                     // for builds that target two waves per SIMD (256 registers)
@@ -858,7 +860,7 @@ solve_kernel(const DevParams P, const int B,
           VROW(u) = t;
         }
       }
-      if (valid) {                             // rotate left by U
+      {                                        // rotate left by U
         f2 tmp[U / 2];
 #pragma unroll
         for (int u = 0; u < U / 2; ++u) tmp[u] = Vr[u];
