@@ -100,6 +100,9 @@ struct IterScratch {
   alignas(16) float r32[H][2][6];   // KKT residual, control space
   alignas(16) float beta[NW];
   alignas(16) float gam[NW];
+  // gamma again, component-major in two groups (torque, force) for the gradient increment; the second group
+  // starts 4 banks after a multiple of 32 so that the two addresses of a read never share a bank
+  alignas(16) float gamT[2][((3 * H + 35) / 32) * 32 + 4 > 3 * H ? ((3 * H + 31) / 32) * 32 + 4 : 3 * H];
   // set-up only
   RT Rv[H][9];               // R_inv (REF:160-164)
   RT Pre[H][9];              // prefix sums of R_inv
@@ -885,7 +888,7 @@ solve_kernel(const DevParams P, const int B,
   // are rebuilt exactly from x at every stopping test, so the fixed point is unchanged.
   RT xo[2] = {0, 0};                          // own variables
   RT zb[2] = {0, 0}, zg[2] = {0, 0}, yb[2] = {0, 0}, yg[2] = {0, 0};
-  RT axg[2] = {0, 0}, bwl = 0;
+  RT axg[2] = {0, 0}, bwl = 0, gbl = qt;     // x = 0: b = 0, gb = qt
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
@@ -926,6 +929,23 @@ solve_kernel(const DevParams P, const int B,
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
         bwl = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
+      sm.u.itv.bwT[c][j] = bwl;
+    }
+    wg_sync<NT>();
+    if (valid) {
+      // gbl = (Gt b + qt)[l] in f64: 3 H doubles of the lane's component group, 3 independent chains
+      static_assert(H % 2 == 0, "the wrench is read in groups of 6");
+      const RT* bsrc = &sm.u.itv.bwT[c < 3 ? 0 : 3][0];
+      RT g0 = qt, g1 = 0, g2 = 0;
+#pragma unroll
+      for (int q = 0; q < 3 * H; q += 6) {
+        RT v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = bsrc[q + k];
+        g0 += (RT)Grow[q] * v[0];     g1 += (RT)Grow[q + 1] * v[1]; g2 += (RT)Grow[q + 2] * v[2];
+        g0 += (RT)Grow[q + 3] * v[3]; g1 += (RT)Grow[q + 4] * v[4]; g2 += (RT)Grow[q + 5] * v[5];
+      }
+      gbl = g0 + (g1 + g2);
     }
   };
 
@@ -940,7 +960,7 @@ solve_kernel(const DevParams P, const int B,
         park(yg[f], pk[8 + f]); park(axg[f], pk[10 + f]); park(irvb[f], pk[12 + f]); park(irvg[f], pk[14 + f]);
         park(lb[f], pk[16 + f]); park(ub[f], pk[18 + f]); park(cmu[f], pk[20 + f]);
       }
-      park(bwl, pk[22]); park(qt, pk[23]);
+      park(gbl, pk[22]); park(qt, pk[23]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) park(mk3[k], pk[24 + k]);
       float pkd[3];
@@ -955,7 +975,7 @@ solve_kernel(const DevParams P, const int B,
         unpark(yg[f], pk[8 + f]); unpark(axg[f], pk[10 + f]); unpark(irvb[f], pk[12 + f]); unpark(irvg[f], pk[14 + f]);
         unpark(lb[f], pk[16 + f]); unpark(ub[f], pk[18 + f]); unpark(cmu[f], pk[20 + f]);
       }
-      unpark(bwl, pk[22]); unpark(qt, pk[23]);
+      unpark(gbl, pk[22]); unpark(qt, pk[23]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) unpark(mk3[k], pk[24 + k]);
 #pragma unroll
@@ -972,29 +992,10 @@ solve_kernel(const DevParams P, const int B,
         wb[f] = yb[f] + rvb[f] * (xo[f] - zb[f]);
         sm.u.itv.wg[j][f][c] = yg[f] + rvg[f] * (axg[f] - zg[f]);
       }
-      sm.u.itv.bwT[c][j] = bwl;
+      sm.u.itv.gb[l] = gbl;
     }
     wg_sync<NT>();
     BMPC_STAMP(0)
-    // --- P1: wrench-space gradient gb = Gt b + qt
-    if (valid) {
-      // 3 H doubles of the lane's component group, 3 independent accumulation chains
-      static_assert(H % 2 == 0, "P1 reads the wrench in groups of 6");
-      const RT* bsrc = &sm.u.itv.bwT[c < 3 ? 0 : 3][0];
-      RT g0 = qt, g1 = 0, g2 = 0;
-#pragma unroll
-      for (int q = 0; q < 3 * H; q += 6) {
-        RT v[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = bsrc[q + k];
-        g0 += (RT)Grow[q] * v[0];     g1 += (RT)Grow[q + 1] * v[1]; g2 += (RT)Grow[q + 2] * v[2];
-        g0 += (RT)Grow[q + 3] * v[3]; g1 += (RT)Grow[q + 4] * v[4]; g2 += (RT)Grow[q + 5] * v[5];
-      }
-      const RT g = g0 + (g1 + g2);
-      sm.u.itv.gb[l] = g;
-    }
-    wg_sync<NT>();
-    BMPC_STAMP(1)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     float lcol[2][6];
     if (valid) {
@@ -1055,6 +1056,7 @@ solve_kernel(const DevParams P, const int B,
       }
       gown = -((a0.x + a0.y) + (a1.x + a1.y));
       sm.u.itv.gam[l] = gown;
+      sm.u.itv.gamT[c < 3 ? 0 : 1][(c < 3 ? c : c - 3) * H + j] = gown;
     }
     wg_sync<NT>();
     BMPC_STAMP(4)
@@ -1125,7 +1127,23 @@ solve_kernel(const DevParams P, const int B,
         xo[f] = alpha * xto + (1 - alpha) * xo[f];
         axg[f] = alpha * ztg + (1 - alpha) * axg[f];
       }
-      bwl -= alpha * (RT)gown;
+      // gb follows b <- b - alpha gamma: gb -= alpha Gt gamma, the increment in f32 (it vanishes with the step)
+      {
+        const float* gsrc = &sm.u.itv.gamT[c < 3 ? 0 : 1][0];
+        f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3 * H; q += 4) {
+          if (q + 4 <= 3 * H) {
+            const float4 g4 = *reinterpret_cast<const float4*>(&gsrc[q]);
+            e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g4.x, g4.y}, e0);
+            e1 = __builtin_elementwise_fma(f2{Grow[q + 2], Grow[q + 3]}, f2{g4.z, g4.w}, e1);
+          } else {
+            const float2 g2 = *reinterpret_cast<const float2*>(&gsrc[q]);
+            e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g2.x, g2.y}, e0);
+          }
+        }
+        gbl -= alpha * (RT)((e0.x + e0.y) + (e1.x + e1.y));
+      }
       if (check_now) {
         // a real (uniform) branch: predicated, this costs ~25 instructions in every iteration
         asm volatile("" ::: "memory");
