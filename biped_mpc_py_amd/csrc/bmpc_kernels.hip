@@ -117,11 +117,12 @@ struct alignas(16) Smem {
   } u;
   RT xs[H][2][6];            // x (relaxed iterate); re-read per iteration instead of living in VGPRs
   alignas(16) float piv[2][Dims<H>::NT];   // sweep pivot column, double buffered (slots >= NW: idle lanes)
-  // block-diagonal part of K^-1
-  alignas(16) float L[H][2][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
-  alignas(16) float Kn[H][2][6][6];     // [0]: Ka^-1, [1]: T Ka^-1   (N Ka^-1 N' applied as N (Ka^-1 (N' r)))
-  alignas(16) float GK[H][2][6][6];     // G_f Kn_f and G_f L_f: the general rows of the step d, from (t, gamma)
-  alignas(16) float GL[H][2][6][6];
+  // block-diagonal part of K^-1.  Foot-major: a lane's row then sits at 24 B x lane + const, which the 32
+  // LDS banks serve without conflicts (step-major interleaves the feet and collides every third step)
+  alignas(16) float L[2][H][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
+  alignas(16) float Kn[2][H][6][6];     // [0]: Ka^-1, [1]: T Ka^-1   (N Ka^-1 N' applied as N (Ka^-1 (N' r)))
+  alignas(16) float GK[2][H][6][6];     // G_f Kn_f and G_f L_f: the general rows of the step d, from (t, gamma)
+  alignas(16) float GL[2][H][6][6];
   // step data
   RT Iw[H][9];               // world inverse inertia
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
@@ -743,7 +744,7 @@ solve_kernel(const DevParams P, const int B,
       }
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        sm.L[j][0][c][b] = (float)l0[b];
+        sm.L[0][j][c][b] = (float)l0[b];
         sm.u.fac.M2[j][c][b] = l0[b];           // L_0 rows for F
         sm.u.fac.M0[j][c][b] = y0[b];           // Ka^-1 D0 W_0^-1 rows for L_1
       }
@@ -758,10 +759,10 @@ solve_kernel(const DevParams P, const int B,
       row_times_mat6(Trow, sm.u.fac.M1[j], sk);     // T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        sm.L[j][1][c][b] = (float)sl[b];
+        sm.L[1][j][c][b] = (float)sl[b];
         // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
-        sm.Kn[j][0][c][b] = (float)ka[0][b];
-        sm.Kn[j][1][c][b] = (float)sk[b];
+        sm.Kn[0][j][c][b] = (float)ka[0][b];
+        sm.Kn[1][j][c][b] = (float)sk[b];
       }
     }
     wg_sync<NT>();
@@ -776,11 +777,11 @@ solve_kernel(const DevParams P, const int B,
           float gk = 0.f, gl = 0.f;
 #pragma unroll
           for (int b = 0; b < 6; ++b) {
-            gk = fmaf(gr[b], sm.Kn[j][f][b][i], gk);
-            gl = fmaf(gr[b], sm.L[j][f][b][i], gl);
+            gk = fmaf(gr[b], sm.Kn[f][j][b][i], gk);
+            gl = fmaf(gr[b], sm.L[f][j][b][i], gl);
           }
-          sm.GK[j][f][c][i] = gk;
-          sm.GL[j][f][c][i] = gl;
+          sm.GK[f][j][c][i] = gk;
+          sm.GL[f][j][c][i] = gl;
         }
       }
     }
@@ -1024,7 +1025,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) lcol[f][i] = sm.L[j][f][i][c];
+        for (int i = 0; i < 6; ++i) lcol[f][i] = sm.L[f][j][i][c];
     }
     wg_sync<NT>();
     BMPC_STAMP(2)
@@ -1071,10 +1072,10 @@ solve_kernel(const DevParams P, const int B,
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          kn[f][i] = sm.Kn[j][f][c][i];
-          gk[f][i] = sm.GK[j][f][c][i];
-          lr[f][i] = sm.L[j][f][c][i];
-          glr[f][i] = sm.GL[j][f][c][i];
+          kn[f][i] = sm.Kn[f][j][c][i];
+          gk[f][i] = sm.GK[f][j][c][i];
+          lr[f][i] = sm.L[f][j][c][i];
+          glr[f][i] = sm.GL[f][j][c][i];
         }
       // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
       float tn[6];
