@@ -8,6 +8,8 @@ from .params import MPC, Biped, pack_params                                  # n
 from .api import (BatchSolver, solve_mpc, solve_mpc_batch, get_contact_sequence,   # noqa: F401
                   phase_index, lowLevelControl, getFootPositionWorld)
 from . import sharding                                                        # noqa: F401
+from ._lib import BmpcError                                                   # noqa: F401
 
 __all__ = ["MPC", "Biped", "pack_params", "BatchSolver", "solve_mpc", "solve_mpc_batch",
-           "get_contact_sequence", "phase_index", "lowLevelControl", "getFootPositionWorld", "sharding"]
+           "get_contact_sequence", "phase_index", "lowLevelControl", "getFootPositionWorld", "sharding",
+           "BmpcError"]

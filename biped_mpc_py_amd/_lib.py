@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -18,7 +18,13 @@ EXPORTS = (
     "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
     "bmpc_foot_position_world", "bmpc_foot_position_world_device",
     "bmpc_low_level_control", "bmpc_low_level_control_device",
+    "bmpc_gait_default", "bmpc_contact_sequence", "bmpc_contact_sequence_device",
 )
+
+
+class CGait(C.Structure):
+    """`bmpc_gait` of include/bmpc.h."""
+    _fields_ = [("period", C.c_int32), ("offset", C.c_int32 * 2), ("duty", C.c_int32 * 2)]
 
 
 class BmpcError(RuntimeError):
@@ -100,6 +106,9 @@ def load():
     lib.bmpc_low_level_control.argtypes = [vp, ip] + [vp] * 8
     lib.bmpc_low_level_control_device.argtypes = [vp, ip] + [vp] * 9
     lib.bmpc_last_kernel_ms.argtypes = [vp, fp]
+    lib.bmpc_gait_default.argtypes = [C.POINTER(CGait), ip]
+    lib.bmpc_contact_sequence.argtypes = [vp, ip, vp, C.POINTER(CGait), vp, vp]
+    lib.bmpc_contact_sequence_device.argtypes = [vp, ip, vp, C.POINTER(CGait), vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "bmpc_last_error":

@@ -28,15 +28,15 @@ def phase_index(t, mpc_or_dt, h=None):
 
 def get_contact_sequence(t, mpc, half=None):
     """REF:50-59.  Default: the reference's 20x2 table of 5-on/5-off, rows k..k+9 (ten rows whatever
-    `mpc.h` is -- reference quirk).  With `half` given: half-on/half-off table, rows k..k+h."""
+    `mpc.h` is -- reference quirk).  With `half` given: the same schedule with that half period, continued
+    periodically, rows k..k+h-1 (what `BatchSolver.contact_sequence` computes on the device)."""
     if half is None:
         half_, nrow = 5, 10
     else:
         half_, nrow = int(half), int(mpc.h)
-    leg0 = (np.arange(4 * half_) // half_) % 2 == 0
-    table = np.stack([leg0, ~leg0], axis=1).astype(int)
     k = phase_index(t, mpc)
-    return table[k:k + nrow, :]
+    leg0 = ((k + np.arange(nrow)) // half_) % 2 == 0
+    return np.stack([leg0, ~leg0], axis=1).astype(int)
 
 
 def _ptr(a):
@@ -174,6 +174,28 @@ class BatchSolver:
         _lib.check(self._lib.bmpc_low_level_control(self._h, B, _ptr(x_fb), _ptr(t), _ptr(pf_w), _ptr(q), _ptr(qd),
                                                     _ptr(c0), _ptr(u0), _ptr(tau)))
         return tau.astype(np.float64)
+
+    def contact_sequence(self, t, period=None, offset=None, duty=None, want_contact=True):
+        """Batched gait scheduler on the device (REF:50-59 and the phase index of REF:99-100).
+        t (B,) fp64 -> phase (B,) int32, contact (B,h,2) uint8.  Default schedule: the reference's, at this
+        solver's half period; otherwise leg g stands at schedule step n iff ((n + offset[g]) % period) < duty[g]."""
+        t = np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1))
+        B = t.shape[0]
+        gait = None
+        if period is not None or offset is not None or duty is not None:
+            gait = _lib.CGait()
+            _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
+            if period is not None:
+                gait.period = int(period)
+            if offset is not None:
+                gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
+            if duty is not None:
+                gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        phase = np.empty(B, np.int32)
+        contact = np.empty((B, self.h, 2), np.uint8) if want_contact else None
+        _lib.check(self._lib.bmpc_contact_sequence(self._h, B, _ptr(t), None if gait is None else C.byref(gait),
+                                                   _ptr(phase), _ptr(contact)))
+        return phase, contact
 
     def last_kernel_ms(self):
         ms = C.c_float(-1.0)

@@ -415,6 +415,61 @@ int bmpc_low_level_control(bmpc_handle h, int B, const float* x_fb, const double
   return BMPC_OK;
 }
 
+int bmpc_gait_default(bmpc_gait* g, int half) {
+  if (!g) return fail(BMPC_ERR_INVALID, "null gait");
+  if (half < 1) return fail(BMPC_ERR_INVALID, "half period must be >= 1");
+  g->period = 2 * half;
+  g->offset[0] = 0; g->offset[1] = half;      // REF:52-55: leg 1 stands first, leg 2 half a period later
+  g->duty[0] = half; g->duty[1] = half;
+  return BMPC_OK;
+}
+
+static int gait_params(bmpc_handle h, const bmpc_gait* gait, bmpc::GaitParams* G) {
+  bmpc_gait g;
+  if (gait) g = *gait;
+  else bmpc_gait_default(&g, h->params.half);
+  if (g.period < 1) return fail(BMPC_ERR_INVALID, "gait period must be >= 1");
+  for (int k = 0; k < 2; ++k)
+    if (g.duty[k] < 0 || g.duty[k] > g.period) return fail(BMPC_ERR_INVALID, "gait duty must be in [0, period]");
+  G->h = h->params.h; G->period = g.period; G->dt = h->params.dt;
+  for (int k = 0; k < 2; ++k) { G->offset[k] = g.offset[k]; G->duty[k] = g.duty[k]; }
+  return BMPC_OK;
+}
+
+int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bmpc_gait* gait, int32_t* phase,
+                                 uint8_t* contact, void* stream) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B == 0) return BMPC_OK;
+  if (!t) return fail(BMPC_ERR_INVALID, "null pointer");
+  bmpc::GaitParams G;
+  int rc = gait_params(h, gait, &G);
+  if (rc != BMPC_OK) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipLaunchKernelGGL(bmpc::gait_kernel, dim3((B + 255) / 256), dim3(256), 0, st, G, B, t, phase, contact);
+  HIP_TRY(hipGetLastError());
+  return BMPC_OK;
+}
+
+int bmpc_contact_sequence(bmpc_handle h, int B, const double* t, const bmpc_gait* gait, int32_t* phase, uint8_t* contact) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (B == 0) return BMPC_OK;
+  if (!t) return fail(BMPC_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B, hh = (size_t)h->params.h;
+  HIP_TRY(h->ll_t.ensure(n)); HIP_TRY(h->phase.ensure(n)); HIP_TRY(h->contact.ensure(n * hh * 2));
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->ll_t.p, t, n * sizeof(double), hipMemcpyHostToDevice, st));
+  int rc = bmpc_contact_sequence_device(h, B, h->ll_t.p, gait, h->phase.p, h->contact.p, st);
+  if (rc != BMPC_OK) return rc;
+  if (phase) HIP_TRY(hipMemcpyAsync(phase, h->phase.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (contact) HIP_TRY(hipMemcpyAsync(contact, h->contact.p, n * hh * 2, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
 int bmpc_debug_set_profile(bmpc_handle h, long long* device_buf) {
   if (!h) return fail(BMPC_ERR_INVALID, "null handle");
   h->prof_dev = device_buf;

@@ -156,4 +156,44 @@ lowlevel_kernel(const LowLevelParams P, const int B, const float* __restrict__ x
   }
 }
 
+// ---- gait scheduler (REF:50-59, generalised) ---------------------------------------------------------
+// phase[b] = int(t[b] // dt) % h with CPython's float floor division (so that times that are multiples of dt
+// up to rounding fall on the side the reference puts them), and rows k .. k+h-1 of a periodic contact
+// schedule: leg g is in stance at step n iff ((n + offset[g]) mod period) < duty[g].  The reference's
+// table (REF:52-55) is period 10, offset {0, 5}, duty {5, 5}.
+struct GaitParams { int h, period, offset[2], duty[2]; double dt; };
+
+__device__ __forceinline__ double py_floordiv(double vx, double wx) {
+  double mod = fmod(vx, wx);
+  double div = (vx - mod) / wx;
+  if (mod != 0.0 && ((wx < 0) != (mod < 0))) div -= 1.0;
+  if (div != 0.0) {
+    double fl = floor(div);
+    if (div - fl > 0.5) fl += 1.0;
+    return fl;
+  }
+  return copysign(0.0, vx / wx);
+}
+
+__global__ void __launch_bounds__(256)
+gait_kernel(const GaitParams G, const int B, const double* __restrict__ t, int32_t* __restrict__ phase,
+            uint8_t* __restrict__ contact) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const double ph = py_floordiv(t[i], G.dt);                           // REF:56
+  // int(ph) % h with Python's sign convention (non-negative for h > 0); |ph| < 2^53 keeps it exact
+  double kd = fmod(ph, (double)G.h);
+  if (kd < 0) kd += (double)G.h;
+  const int k = (int)kd;                                                // REF:57
+  if (phase) phase[i] = k;
+  if (contact) {
+    for (int n = 0; n < G.h; ++n)                                       // REF:58: rows k .. k+h-1
+      for (int g = 0; g < 2; ++g) {
+        int m = (k + n + G.offset[g]) % G.period;
+        if (m < 0) m += G.period;
+        contact[((size_t)i * G.h + n) * 2 + g] = m < G.duty[g] ? 1 : 0;
+      }
+  }
+}
+
 }  // namespace bmpc

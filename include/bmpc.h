@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 2
+#define BMPC_ABI_VERSION 3
 
 enum bmpc_status {
   BMPC_OK = 0,
@@ -165,6 +165,23 @@ int bmpc_low_level_control(bmpc_handle h, int B, const float* x_fb, const double
 int bmpc_low_level_control_device(bmpc_handle h, int B, const float* x_fb, const double* t, const float* pf_w,
                                   const float* q, const float* qd, const uint8_t* contact0, const float* u0,
                                   float* tau, void* stream);
+
+/* Gait scheduler, batched (replaces get_contact_sequence REF:50-59 and the phase index of REF:99-100;
+ * SURVEY 8(f) row 2).  phase[b] = int(t[b] // dt) % h in fp64 with Python's float floor division, and
+ * contact[b][n][g] = 1 iff leg g is in stance at schedule step k + n:  ((k + n + offset[g]) mod period) < duty[g].
+ * bmpc_gait_default(g, half) gives the reference's table generalised to a half period: period = 2 half,
+ * offset = {0, half}, duty = {half, half} (half = 5: exactly REF:52-55).  Either output may be NULL.
+ * h and dt are the handle's parameters; `contact` has h rows per instance (the reference slices ten rows
+ * whatever mpc.h is -- identical for its h = 10). */
+typedef struct bmpc_gait {
+  int32_t period;
+  int32_t offset[2];
+  int32_t duty[2];
+} bmpc_gait;
+int bmpc_gait_default(bmpc_gait* g, int half);
+int bmpc_contact_sequence(bmpc_handle h, int B, const double* t, const bmpc_gait* gait, int32_t* phase, uint8_t* contact);
+int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bmpc_gait* gait, int32_t* phase,
+                                 uint8_t* contact, void* stream);
 
 /* Diagnostics: when device_buf (DEVICE pointer, [max_batch][16] int64) is non-NULL every later solve
  * writes per-instance shader-clock stamps {setup, block algebra, dense sweeps, total, iters,

@@ -234,3 +234,50 @@ def test_edge_inputs_and_parameter_changes():
         _, ref = orc.solve_mpc(d["x_fb"][i].astype(np.float32).astype(float), 0.0, d["foot"][i].astype(np.float32).astype(float),
                                om, ob, d["contact"][i])
         assert util.rel_err(c2[i][None], ref[None]).max() <= util.REL_TOL
+
+
+def test_gait_scheduler_on_device():
+    """batched get_contact_sequence / phase index (REF:50-59, 99-100) on the device, against
+    the tables captured from the reference, against the host mirror (Python's float floor division), and a
+    general periodic schedule against its definition."""
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import api
+
+    # 1. the reference's own tables (captured by oracle/gen_golden.py)
+    d = util.load("unit_functions")
+    mpc = bm.MPC()
+    s = bm.BatchSolver(mpc=mpc, max_batch=8192)
+    t_ref = np.asarray(d["t_list"], float)
+    phase, contact = s.contact_sequence(t_ref)
+    for i, t in enumerate(t_ref):
+        assert np.array_equal(contact[i], np.asarray(d["contact_seq"][i], np.uint8))
+        assert phase[i] == api.phase_index(float(t), mpc)
+    # 2. times on and next to the step boundaries, where t // dt is decided by rounding
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 4000, 3000)
+    t = np.concatenate([k * mpc.dt, np.nextafter(k * mpc.dt, np.inf), np.nextafter(k * mpc.dt, -np.inf),
+                        (k * 0.01) * 4.0, rng.uniform(0, 200, 3000), [0.0, 0.12, 0.28, 0.36, 1e-300]])[:8192]
+    phase, contact = s.contact_sequence(t)
+    want_phase = np.array([api.phase_index(float(x), mpc) for x in t])
+    assert np.array_equal(phase, want_phase)
+    for i in rng.integers(0, len(t), 200):
+        assert np.array_equal(contact[i], api.get_contact_sequence(float(t[i]), mpc).astype(np.uint8))
+    s.close()
+    # 3. other horizons / half periods (BASELINE configs 3, 5) against the host mirror
+    for h, half in ((16, 8), (20, 5)):
+        m2 = bm.MPC()
+        m2.h = h
+        s2 = bm.BatchSolver(mpc=m2, half=half, max_batch=512)
+        t2 = rng.uniform(0, 50, 512)
+        ph2, c2 = s2.contact_sequence(t2)
+        for i in range(0, 512, 7):
+            assert ph2[i] == api.phase_index(float(t2[i]), m2)
+            assert np.array_equal(c2[i], api.get_contact_sequence(float(t2[i]), m2, half=half).astype(np.uint8))
+        # 4. a general schedule: period 12, leg offsets 0 / 7, duties 9 / 4 (overlap and flight phases)
+        ph3, c3 = s2.contact_sequence(t2, period=12, offset=(0, 7), duty=(9, 4))
+        n = ph3[:, None] + np.arange(h)[None, :]
+        want = np.stack([((n + 0) % 12) < 9, ((n + 7) % 12) < 4], axis=2).astype(np.uint8)
+        assert np.array_equal(ph3, ph2) and np.array_equal(c3, want)
+        with pytest.raises(bm.BmpcError):
+            s2.contact_sequence(t2, period=12, duty=(13, 4))
+        s2.close()
