@@ -119,10 +119,10 @@ struct alignas(16) Smem {
   alignas(16) float piv[2][Dims<H>::NT];   // sweep pivot column, double buffered (slots >= NW: idle lanes)
   // block-diagonal part of K^-1.  Foot-major: a lane's row then sits at 24 B x lane + const, which the 32
   // LDS banks serve without conflicts (step-major interleaves the feet and collides every third step)
-  alignas(16) float L[2][H][6][6];      // L_j = D^-1 W' F       [foot][var][wrench comp]
-  alignas(16) float Kn[2][H][6][6];     // [0]: Ka^-1, [1]: T Ka^-1   (N Ka^-1 N' applied as N (Ka^-1 (N' r)))
-  alignas(16) float GK[2][H][6][6];     // G_f Kn_f and G_f L_f: the general rows of the step d, from (t, gamma)
-  alignas(16) float GL[2][H][6][6];
+  // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
+  // products against (t, gamma) and run as one packed FMA per term.
+  alignas(16) float LG[2][H][6][6][2];  // {L, G L}:   L_j = D^-1 W' F            [foot][step][var][wrench comp]
+  alignas(16) float KG[2][H][6][6][2];  // {Kn, G Kn}: Kn = Ka^-1 (foot 0), T Ka^-1 (foot 1); N Ka^-1 N' r = N (Ka^-1 (N' r))
   // step data
   RT Iw[H][9];               // world inverse inertia
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
@@ -744,7 +744,7 @@ solve_kernel(const DevParams P, const int B,
       }
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        sm.L[0][j][c][b] = (float)l0[b];
+        sm.LG[0][j][c][b][0] = (float)l0[b];
         sm.u.fac.M2[j][c][b] = l0[b];           // L_0 rows for F
         sm.u.fac.M0[j][c][b] = y0[b];           // Ka^-1 D0 W_0^-1 rows for L_1
       }
@@ -759,10 +759,10 @@ solve_kernel(const DevParams P, const int B,
       row_times_mat6(Trow, sm.u.fac.M1[j], sk);     // T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        sm.L[1][j][c][b] = (float)sl[b];
+        sm.LG[1][j][c][b][0] = (float)sl[b];
         // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
-        sm.Kn[0][j][c][b] = (float)ka[0][b];
-        sm.Kn[1][j][c][b] = (float)sk[b];
+        sm.KG[0][j][c][b][0] = (float)ka[0][b];
+        sm.KG[1][j][c][b][0] = (float)sk[b];
       }
     }
     wg_sync<NT>();
@@ -777,11 +777,11 @@ solve_kernel(const DevParams P, const int B,
           float gk = 0.f, gl = 0.f;
 #pragma unroll
           for (int b = 0; b < 6; ++b) {
-            gk = fmaf(gr[b], sm.Kn[f][j][b][i], gk);
-            gl = fmaf(gr[b], sm.L[f][j][b][i], gl);
+            gk = fmaf(gr[b], sm.KG[f][j][b][i][0], gk);
+            gl = fmaf(gr[b], sm.LG[f][j][b][i][0], gl);
           }
-          sm.GK[f][j][c][i] = gk;
-          sm.GL[f][j][c][i] = gl;
+          sm.KG[f][j][c][i][1] = gk;
+          sm.LG[f][j][c][i][1] = gl;
         }
       }
     }
@@ -1025,7 +1025,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) lcol[f][i] = sm.L[f][j][i][c];
+        for (int i = 0; i < 6; ++i) lcol[f][i] = sm.LG[f][j][i][c][0];
     }
     wg_sync<NT>();
     BMPC_STAMP(2)
@@ -1046,7 +1046,7 @@ solve_kernel(const DevParams P, const int B,
     BMPC_STAMP(3)
     // --- P4: gamma = V beta   (Vr holds -V)
     float gown = 0.f;
-    float kn[2][6], gk[2][6], lr[2][6], glr[2][6];     // rows c of Kn, GK, L, GL for P5
+    f2 kg[2][6], lg[2][6];                             // rows c of {Kn, G Kn} and {L, G L} for P5
     if (valid) {
       f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
@@ -1072,10 +1072,8 @@ solve_kernel(const DevParams P, const int B,
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          kn[f][i] = sm.Kn[f][j][c][i];
-          gk[f][i] = sm.GK[f][j][c][i];
-          lr[f][i] = sm.L[f][j][c][i];
-          glr[f][i] = sm.GL[f][j][c][i];
+          kg[f][i] = *reinterpret_cast<const f2*>(&sm.KG[f][j][c][i][0]);
+          lg[f][i] = *reinterpret_cast<const f2*>(&sm.LG[f][j][c][i][0]);
         }
       // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
       float tn[6];
@@ -1091,18 +1089,13 @@ solve_kernel(const DevParams P, const int B,
       RT st_pb[2], st_pg[2], st_x[2], st_g[2], st_dx[2];     // residual statistics inputs (used at stopping tests)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        float s = 0.f, sg = 0.f;
+        f2 dd = {0.f, 0.f};                     // {d_f[c], (G_f d_f)[c]}
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          s = fmaf(kn[f][i], tn[i], s);
-          sg = fmaf(gk[f][i], tn[i], sg);
-        }
-        if (f == 1) { s = -s; sg = -sg; }
+        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(kg[f][i], f2{tn[i], tn[i]}, dd);
+        if (f == 1) dd = -dd;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          s = fmaf(lr[f][i], gm[i], s);
-          sg = fmaf(glr[f][i], gm[i], sg);
-        }
+        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(lg[f][i], f2{gm[i], gm[i]}, dd);
+        const float s = dd.x, sg = dd.y;
         const RT xto = xo[f] - (RT)s;
         const RT ztg = axg[f] - (RT)sg;
         const RT ztb = xto;
