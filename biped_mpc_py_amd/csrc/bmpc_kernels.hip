@@ -17,7 +17,8 @@
 //   * wrench row c of step j (tau_xyz, F_xyz): one row of Gt and of V = (Gt + F)^-1 in VGPRs,
 //   * control variable c of both feet at step j (v = [f(3), m(3)] per foot),
 //   * the box row of those two variables and general row c (4 friction + 2 line-foot) of both feet.
-// Arithmetic: data and the preconditioner K^-1 (V sweep, V mat-vec, 6x6 blocks) are f32; the
+// Arithmetic: data and the application of the preconditioner K^-1 (V sweep, V mat-vec, stored 6x6
+// factors) are f32, the sweep and mat-vecs on the packed-f32 pipe; the 6x6 block algebra, the
 // iterates and the KKT residual the preconditioner is applied to are RT (f64 by default), which is
 // what pins the fixed point to the fp64 optimum.
 
@@ -581,7 +582,7 @@ solve_kernel(const DevParams P, const int B,
     }
   }
 
-  // ------------------------------------------------------------------ D. factor: L, Na, V for penalties rv
+  // ------------------------------------------------------------------ D. factor: L, Kn (and their G images), V for penalties rv
   RT rvb[2], rvg[2];                          // penalties of this lane's box rows / general rows (f32 values)
 #pragma unroll
   for (int f = 0; f < 2; ++f) { rvb[f] = (RT)(eqb[f] ? P.rho_eq : P.rho); rvg[f] = (RT)P.rho; }
