@@ -197,6 +197,33 @@ class BatchSolver:
                                                    _ptr(phase), _ptr(contact)))
         return phase, contact
 
+    def contact_sequence_device(self, t, phase=None, contact=None, period=None, offset=None, duty=None, stream=None):
+        """`contact_sequence` on device tensors: t (B,) float64 CUDA tensor -> (phase int32 (B,), contact uint8
+        (B,h,2)), asynchronous on `stream` (default: torch's current stream); nothing crosses PCIe."""
+        import torch
+        dev = t.device
+        if dev.type != "cuda" or dev.index != self.device or t.dtype != torch.float64 or not t.is_contiguous():
+            raise ValueError(f"t must be a contiguous float64 tensor on cuda:{self.device}")
+        B = t.shape[0]
+        if phase is None:
+            phase = torch.empty(B, dtype=torch.int32, device=dev)
+        if contact is None:
+            contact = torch.empty((B, self.h, 2), dtype=torch.uint8, device=dev)
+        gait = None
+        if period is not None or offset is not None or duty is not None:
+            gait = _lib.CGait()
+            _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
+            if period is not None:
+                gait.period = int(period)
+            if offset is not None:
+                gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
+            if duty is not None:
+                gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(self._lib.bmpc_contact_sequence_device(self._h, B, t.data_ptr(), None if gait is None else C.byref(gait),
+                                                          phase.data_ptr(), contact.data_ptr(), st))
+        return phase, contact
+
     def last_kernel_ms(self):
         ms = C.c_float(-1.0)
         _lib.check(self._lib.bmpc_last_kernel_ms(self._h, C.byref(ms)))

@@ -281,3 +281,40 @@ def test_gait_scheduler_on_device():
         with pytest.raises(bm.BmpcError):
             s2.contact_sequence(t2, period=12, duty=(13, 4))
         s2.close()
+
+
+def test_device_resident_control_step():
+    """One control step without host arithmetic: t -> (phase, contact) -> solve -> states[:, 0] on device tensors,
+    against the host-pointer path on the same inputs; from rest the loop holds F_z = m g."""
+    import torch
+    import biped_mpc_py_amd as bm
+    mpc, biped = bm.MPC(), bm.Biped()
+    B = 64
+    dev = torch.device("cuda", 0)
+    s = bm.BatchSolver(mpc=mpc, biped=biped, max_batch=B)
+    x0 = np.zeros((B, 12), np.float32)
+    x0[:, 5] = 0.55
+    foot = np.tile(np.array([-0.0195, 0.089, 0, -0.0195, -0.089, 0], np.float32), (B, 1))
+    t_host = np.linspace(0.0, 2.0, B)
+    t = torch.from_numpy(t_host).to(dev)
+    x_fb, foot_t = torch.from_numpy(x0).to(dev), torch.from_numpy(foot).to(dev)
+    states = torch.empty((B, mpc.h, 13), dtype=torch.float32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    phase, contact = s.contact_sequence_device(t, period=10, duty=(10, 10))       # both legs in stance
+    assert contact.dtype == torch.uint8 and bool((contact == 1).all())
+    ph_h, _ = s.contact_sequence(t_host, want_contact=False)
+    assert np.array_equal(phase.cpu().numpy(), ph_h)
+    for _ in range(8):
+        controls, _ = s.solve_device(x_fb, foot_t, contact, phase, states=states, status=status)
+        x_fb = states[:, 0, :12].contiguous()
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0
+    u = controls.cpu().numpy()
+    assert np.abs(u[:, 0, 2] + u[:, 0, 5] - biped.m * biped.g).max() < 0.3       # holds the weight (transient of the fp64 oracle loop: 0.1 N at this step)
+    assert np.abs(x_fb.cpu().numpy()[:, 5] - 0.55).max() < 1e-3
+    # same inputs through the host-pointer path
+    _, u_h, info = s.solve(x_fb.cpu().numpy(), foot, contact.cpu().numpy(), phase.cpu().numpy(), want_states=False)
+    c2, _ = s.solve_device(x_fb, foot_t, contact, phase)
+    torch.cuda.synchronize()
+    assert np.array_equal(c2.cpu().numpy().astype(np.float64), u_h)
+    s.close()
