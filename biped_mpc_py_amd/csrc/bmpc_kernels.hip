@@ -894,6 +894,8 @@ solve_kernel(const DevParams P, const int B,
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
+  int n_check = 0;
+  constexpr int REFRESH_CHECKS = 2;            // identical iterates and parity for 1, 2 and 4 on every test set
   int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
   while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
   float res_p = 0.f, res_s = 0.f;
@@ -1157,14 +1159,18 @@ solve_kernel(const DevParams P, const int B,
     // --- stopping test (workgroup-uniform); the carried products are rebuilt from x first
     if (check_now) {
       next_check += P.check_every;
-      refresh();
       float v4[4] = {rp, rs, nz, nx};
       block_max4<NT>(v4, sm.red);
       res_p = v4[0];
       res_s = v4[1];
       const bool bad = !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
+      const bool done = v4[0] <= P.eps_pri * fmaxf(1.f, v4[2]) && v4[1] <= P.eps_dua * fmaxf(1.f, v4[3]);
+      // the exact rebuild of the carried products: before leaving (the outputs use it) and at every
+      // REFRESH_CHECKS-th test otherwise
+      ++n_check;
+      if (bad || done || it == P.max_iter || n_check % REFRESH_CHECKS == 0) refresh();
       if (bad) { status = 2; break; }
-      if (v4[0] <= P.eps_pri * fmaxf(1.f, v4[2]) && v4[1] <= P.eps_dua * fmaxf(1.f, v4[3])) { status = 0; break; }
+      if (done) { status = 0; break; }
     }
     // --- penalty re-classification by the current active set
     if (it == next_adapt) {
