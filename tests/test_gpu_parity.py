@@ -318,3 +318,22 @@ def test_device_resident_control_step():
     torch.cuda.synchronize()
     assert np.array_equal(c2.cpu().numpy().astype(np.float64), u_h)
     s.close()
+
+
+@pytest.mark.parametrize("name", ["big_stand10", "big_mixed10", "big_walk16", "big_walk20"])
+def test_oracle_solved_sets(name):
+    """768 random instances of the BASELINE config shapes solved by the fp64 oracle (tests/gen_tuning_sets.py):
+    every instance converges and matches to the north_star tolerance."""
+    import os
+    import biped_mpc_py_amd as bm
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tuning", name + ".npz"))
+    mpc = bm.MPC()
+    mpc.h = int(z["h"])
+    s = bm.BatchSolver(mpc=mpc, half=int(z["half"]), max_batch=len(z["x_fb"]))
+    mu = z["mu"] if z["mu"].size else None
+    _, u, info = s.solve(z["x_fb"], z["foot"], z["contact"], z["phase"], x_cmd=z["x_cmd"], mu=mu, want_states=False)
+    s.close()
+    ref = z["ref"]
+    rel = np.abs(u - ref).reshape(len(u), -1).max(1) / np.maximum(1.0, np.abs(ref).reshape(len(u), -1).max(1))
+    assert int((info["status"] != 0).sum()) == 0
+    assert rel.max() <= util.REL_TOL, rel.max()

@@ -2,10 +2,10 @@
 
 For every combination given on the command line (name=v1,v2,... ...) it reports, on oracle-solved
 sample sets (npz files with x_fb, foot, contact, phase, x_cmd, mu, ref) the worst relative force
-error, the instances that did not converge, mean iterations / factorisations, and the kernel time
+error (sets: tests/gen_tuning_sets.py), the instances that did not converge, mean iterations / factorisations, and the kernel time
 of the BASELINE configs[1] batch (4096 standing instances, h = 10).
 
-    python tools/param_sweep.py build_tmp kappa=10,30 adapt_every=10,15
+    python tools/param_sweep.py tests/golden/tuning kappa=10,30 adapt_every=10,15
 """
 import itertools
 import os
