@@ -174,7 +174,7 @@ int bmpc_default_params(bmpc_params* p, int h) {
   for (int i = 0; i < 3; ++i) p->tau_min[i] = -p->tau_max[i];         // REF:48
   p->rho = 0.03; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 20.0;
   p->alpha = 1.6; p->eps_pri = 1e-7; p->eps_dua = 1e-7;
-  p->max_iter = 400; p->check_every = 5; p->adapt_start = 10; p->adapt_every = 10; p->max_refactor = 40;
+  p->max_iter = 400; p->check_every = 5; p->adapt_start = 10; p->adapt_every = 10; p->max_refactor = 24;
   p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
   p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31
   p->swingHeight = 0.1;                                               // REF:32

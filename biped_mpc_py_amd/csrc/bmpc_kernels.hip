@@ -1178,6 +1178,11 @@ solve_kernel(const DevParams P, const int B,
       if (nfac <= P.max_refactor) {
       int changed = 0;
       float nb[2], ng[2];
+      // Damping: an instance that is still re-classifying after many rounds is cycling between active sets
+      // (about one in a million at kappa = 20); smaller moves break the cycle (sqrt(kappa) after 10
+      // factorisations, its square root after 16), where stopping the adaptation would leave hundreds of
+      // plain-ADMM iterations.
+      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
       if (valid) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -1186,8 +1191,8 @@ solve_kernel(const DevParams P, const int B,
           // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
           const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
           const float ob = (float)rvb[f], og = (float)rvg[f];
-          nb[f] = eqb[f] ? P.rho_eq : (actb ? fminf(ob * P.kappa, hib) : fmaxf(ob / P.kappa, P.rho_lo));
-          ng[f] = actg ? fminf(og * P.kappa, hig) : fmaxf(og / P.kappa, P.rho_lo);
+          nb[f] = eqb[f] ? P.rho_eq : (actb ? fminf(ob * kap, hib) : fmaxf(ob / kap, P.rho_lo));
+          ng[f] = actg ? fminf(og * kap, hig) : fmaxf(og / kap, P.rho_lo);
           changed |= (nb[f] != ob) | (ng[f] != og);
         }
       }

@@ -63,7 +63,7 @@ class Params:
         self.check_every = 5
         self.eps_pri = 1e-7
         self.eps_dua = 1e-7
-        self.max_refactor = 40
+        self.max_refactor = 24
 
 
 def _skew(v):
@@ -325,8 +325,11 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
                 none = cnt_act == 0
                 rnew = np.where(eq, rho_eq, np.where(full, hi, np.where(none, dt_(P.rho_lo), rho0))).astype(dtp)
             elif P.kappa:
-                up = np.minimum(rv * dt_(P.kappa), hi)
-                dn = np.maximum(rv / dt_(P.kappa), dt_(P.rho_lo))
+                # damping as in the kernel: sqrt(kappa) after 10 factorisations, its square root after 16
+                kap = np.where(n_factor <= 10, P.kappa, np.where(n_factor <= 16, P.kappa ** 0.5, P.kappa ** 0.25))
+                kap = kap.astype(dtp)[:, None, None, None]
+                up = np.minimum(rv * kap, hi)
+                dn = np.maximum(rv / kap, dt_(P.rho_lo))
                 rnew = np.where(eq, rho_eq, np.where(act, up, dn)).astype(dtp)
             else:
                 rnew = np.where(eq, rho_eq, np.where(act, hi, dt_(P.rho_lo))).astype(dtp)
