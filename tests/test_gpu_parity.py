@@ -337,3 +337,19 @@ def test_oracle_solved_sets(name):
     rel = np.abs(u - ref).reshape(len(u), -1).max(1) / np.maximum(1.0, np.abs(ref).reshape(len(u), -1).max(1))
     assert int((info["status"] != 0).sum()) == 0
     assert rel.max() <= util.REL_TOL, rel.max()
+
+
+@pytest.mark.parametrize("h,seed,kw", [(16, 306, dict(vx_cmd=True)), (20, 205, dict(vx_cmd=True, per_step_mu=True))])
+def test_rare_active_set_cycles_are_damped(h, seed, kw):
+    """Two batches in which one instance used to cycle between two active sets until max_iter (found by a
+    2 M-instance soak at kappa = 20): with the damped late moves every instance converges in < 300 iterations."""
+    import biped_mpc_py_amd as bm
+    B = 16384
+    s = util.synth_batch(B, h, seed, gait="walking", **kw)
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
+    sol.close()
+    assert int((info["status"] != 0).sum()) == 0
+    assert int(info["iters"].max()) < 300 and not np.isnan(u).any()
