@@ -1,0 +1,18 @@
+"""Convergence soak (GPU box): random batches of the four BASELINE config shapes over a range of seeds; prints the
+instances that did not converge and the worst iteration count.  python tools/soak.py"""
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd())
+import biped_mpc_py_amd as bm
+from tests import util
+tot=0; bad=0; worst=0
+for h, gait, kw in ((10,'mixed',dict(vx_cmd=True)), (10,'standing',{}), (16,'walking',dict(vx_cmd=True)), (20,'walking',dict(vx_cmd=True, per_step_mu=True))):
+    mpc=bm.MPC(); mpc.h=h
+    B=65536 if h==10 else 16384
+    for seed in range(500, 540):
+        s=util.synth_batch(B,h,seed,gait=gait,**kw)
+        sol=bm.BatchSolver(mpc=mpc, half=s['half'], max_batch=B)
+        _,u,info=sol.solve(s['x_fb'],s['foot'],s['contact'],s['phase'],x_cmd=s['x_cmd'],mu=s['mu'],want_states=False)
+        sol.close()
+        nb=int((info['status']!=0).sum()); tot+=B; bad+=nb; worst=max(worst,int(info['iters'].max()))
+        print(h,gait,seed,'not converged',nb,'iters mean %.1f max %d'%(info['iters'].mean(), info['iters'].max()), 'nan', int(np.isnan(u).any()), flush=True)
+print('TOTAL', tot, 'instances, not converged', bad, 'worst iterations', worst)
