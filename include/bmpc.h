@@ -67,14 +67,16 @@ typedef struct bmpc_params {
   double rho_hi_f;           /* ceiling for force-like rows (force box, friction) */
   double rho_hi_m;           /* ceiling for moment-like rows (moment box, line-foot) */
   double kappa;              /* per re-classification a row's penalty moves by this factor: up
-                                (towards its ceiling) if the row is active, down (towards rho_lo) if not */
+                                (towards its ceiling) if the row is active, down (towards rho_lo) if not;
+                                damped to sqrt(kappa) after 10 factorisations of an instance, to its
+                                fourth root after 16 (rare active-set cycles) */
   double alpha;              /* over-relaxation */
   double eps_pri, eps_dua;   /* relative stopping tolerances */
   int32_t max_iter;
   int32_t check_every;       /* stopping test period */
   int32_t adapt_start;       /* first penalty re-classification */
   int32_t adapt_every;       /* re-classification period (0 = never) */
-  int32_t max_refactor;      /* cap on re-factorisations per instance */
+  int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached) */
   int32_t reserved;
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
   double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
