@@ -1,108 +1,218 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MPC hot path on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch: `bmpc_solve_batch_device` on B = 4096
-randomised CoM / stance states, horizon 10, double support (BASELINE.json configs[1]), inputs
-already resident in HBM.  With --gpus N the driver launches one rank per GPU (torchrun env); every
-rank solves its own 4096 instances (weak scaling, no data-path collective: instances are
-independent); the timed region is bracketed by barrier + synchronize and the slowest
-rank's time is used.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch: `bmpc_solve_batch_device` on synthetic randomised
+CoM / stance states (SURVEY 8(d) generator), inputs already resident in HBM.  Default workload:
+BASELINE.json configs[1] (B = 4096 per GPU, horizon 10, double support).
 
-Extra objects on the line:
-  roofline      dominant (only) kernel: algorithmic flops per launch / average launch duration,
-                measured with events on the launch stream over the timed region.
-  cpu_baseline  the fp64 oracle (oracle/bmpc_oracle.py = CPU port of the reference path) on a bounded
-                sample of the same workload over the host cores (N = 1, rank 0 only).
+    python bench.py [--gpus N] [--steps K] [--warmup W]            the driver's contract
+    python bench.py --config {2,3,4,5}                              another BASELINE config (own roofline line)
+    python bench.py --gpus 8 --config 4 --scaling strong            ONE 65536 batch sharded N ways
+
+--gpus N > 1 works with or without a launcher: under torch.distributed.run (RANK / WORLD_SIZE in the
+environment) this process is one rank; started bare, it spawns the N ranks itself -- before torch or HIP is
+touched, as child processes, never by exec -- and relays rank 0's JSON line.  One process per GPU,
+backend "nccl" (= RCCL over xGMI).
+
+What a multi-GPU step contains (instances are independent, SURVEY 8(e): no exchange step inside the solve):
+  weak   every rank solves its own `--batch` instances, then the results are collected with ONE RCCL
+         all_gather of the controls (the north_star's "gather"); value = N * batch * steps / time.
+  strong ONE seeded batch of `--total` instances; per step: RCCL broadcast of the ~0.7 KB parameter block,
+         every rank solves its contiguous shard, all_gather of the controls; afterwards rank 0 solves the
+         whole batch alone and the gathered controls must equal that bit for bit.
+The timed region is bracketed by barrier + synchronize on both sides; the slowest rank's time counts.
+
+Extra objects on the JSON line:
+  roofline      the (only) kernel of the path: algorithmic flops per launch / average launch duration,
+                measured with HIP events around every launch on the launch stream;
+                two counts: SURVEY 8(d)'s dense condensed-ADMM formula (`achieved`) and the flops of the
+                algorithm actually run, symmetric work counted once (`achieved_minimal`).
+  cpu_baseline  the reference-style CPU path (dense np.kron assembly as REF:203-286 + a plain fp64 interior
+                point solve, oracle/bmpc_oracle.py) on a bounded sample of the same workload: single-core
+                latency split into assembly / solve, and the all-core rate (N = 1, rank 0 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-H = 10
-BATCH = 4096
 MAX_CPU_WORKERS = 16
 PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md)
 
 
-def synth(B, h, seed):
-    """SURVEY 8(d) generator, config 2 (standing, double support, reference x_cmd)."""
-    rng = np.random.default_rng(seed)
-    x_fb = np.concatenate([
-        rng.uniform(-0.2, 0.2, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(0.45, 0.60, (B, 1)),
-        rng.uniform(-0.5, 0.5, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(-0.2, 0.2, (B, 1))], 1)
-    foot = np.zeros((B, 6))
-    for j, sgn in enumerate((1.0, -1.0)):
-        foot[:, 3 * j + 0] = x_fb[:, 3] - 0.0195 + rng.uniform(-0.05, 0.05, B)
-        foot[:, 3 * j + 1] = x_fb[:, 4] + sgn * (0.089 + rng.uniform(-0.03, 0.03, B))
-    contact = np.ones((B, h, 2), np.uint8)
-    phase = np.zeros(B, np.int32)
-    return x_fb.astype(np.float32), foot.astype(np.float32), contact, phase
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json config number (1-based)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--batch", type=int, default=None, help="weak: instances per GPU per step (default 4096)")
+    ap.add_argument("--total", type=int, default=None, help="strong: instances in the one global batch (default 65536)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the results on their ranks")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="instances for the all-core CPU baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (1-GPU box, use with --backend gloo)")
+    return ap.parse_args(argv)
 
 
-def flops_per_solve(h, iters, nfactor):
-    """Algorithmic flops of one solve (1 MAC = 2 flops), DESIGN.md section 6.
-    set-up: wrench-space Hessian rows + gradient; factor: 6x6 block algebra + the 6h x 6h sweep;
-    iteration: sparse constraint products, Gt mat-vec, block-diagonal + dense K^-1 application."""
+# ------------------------------------------------------------------------------------------ self-launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Started without a launcher: run the N ranks as children (this parent never initialises the GPU,
+    nothing is exec'ed) and relay rank 0's JSON line.  A failing rank takes the others down with it."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    out0 = b""
+    while pending:
+        for r in sorted(pending):
+            if r == 0:
+                try:
+                    o, _ = procs[0].communicate(timeout=0.5)
+                    out0 += o or b""
+                except subprocess.TimeoutExpired:
+                    continue
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                rc = rc or code
+                for q in pending:                         # a dead rank leaves the others in a collective
+                    procs[q].kill()
+        time.sleep(0.2)
+    for line in out0.decode("utf-8", "replace").splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ flop counts
+def flops_survey(h, iters):
+    """dense condensed-ADMM algorithm, F(h, k) = F_setup(h) + k F_iter(h), n = 12h, nx = 13h."""
+    n, nx = 12 * h, 13 * h
+    f_setup = 4056 * h * (h - 1) / 2 + n * (n + 1) * nx + (2 * n * nx + 338 * h) + n ** 3 / 3 + 2 * nx * n
+    f_iter = 2 * n * n + 640 * h
+    return f_setup + iters * f_iter
+
+
+def flops_run(h, iters, nfactor):
+    """Flops of the algorithm that runs (1 MAC = 2 flops), DESIGN.md section 6: set-up of the wrench-space
+    Hessian rows and gradient; per factorisation the 6x6 block algebra and the explicit symmetric inverse
+    of the 6h x 6h matrix (n^3 flops: symmetric work counted once); per iteration the sparse constraint
+    products, the G~ mat-vec and the application of K^-1."""
     n = 6 * h
     f_setup = 2.0 * (27 * h * (h - 1) / 2 + 9 * h * h * (h + 1) / 2 + 40 * h * h)
-    f_factor = 2.0 * (n ** 3 + 3500 * h)
+    f_factor = 1.0 * n ** 3 + 2.0 * 3500 * h
     f_iter = 2.0 * h * (690 + 48 * h)
     return f_setup + nfactor * f_factor + iters * f_iter, dict(setup=f_setup, factor=f_factor, iteration=f_iter)
 
 
-def _oracle_one(args):
-    x, f, c = args
+def hbm_bytes_per_solve(h, x_cmd, mu):
+    """SURVEY 8(d) compulsory I/O: x_fb, foot, phase, contact (u8) [+ x_cmd] [+ mu] in; controls, states,
+    iters / status / nfactor / residuals out."""
+    return 4 * (12 + 6 + 1) + 2 * h + (48 if x_cmd else 0) + (8 * h if mu else 0) + 4 * 25 * h + 20
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_init():
     from threadpoolctl import threadpool_limits
+    global _TP_LIMIT
+    _TP_LIMIT = threadpool_limits(limits=1)
+    from oracle import bmpc_oracle as orc          # noqa: F401  (import cost paid before the timed map)
+    import scipy.optimize                          # noqa: F401
+
+
+def _cpu_one(args):
+    """One instance the way the reference does it: dense assembly of P, q, G, h, A, b (REF:203-286), then a
+    plain fp64 interior point solve (what REF:297 asks cvxopt for).  `full` adds the oracle's polish."""
+    x, t, f, c, xc, mu, h, half, full = args
+    import numpy as np
     from oracle import bmpc_oracle as orc
-    with threadpool_limits(limits=1):
-        t0 = time.perf_counter()
-        _, ctrl = orc.solve_mpc(x, 0.0, f, orc.MPC(), orc.Biped(), c)
-        return ctrl, time.perf_counter() - t0
+    mpc, bp = orc.MPC(), orc.Biped()
+    mpc.h = h
+    if xc is not None:
+        mpc.x_cmd = np.asarray(xc, float)
+    t0 = time.perf_counter()
+    sp = orc.build_sparse_qp(x, t, f, mpc, bp, c, half=half, mu_steps=mu)
+    t1 = time.perf_counter()
+    z, _, _, _ = orc.solve_qp(sp["P"], sp["q"], sp["G"], sp["h"], sp["A"], sp["b"], 13 * h, polish=full)
+    t2 = time.perf_counter()
+    return z[13 * h:].reshape(h, 12), t1 - t0, t2 - t1
 
 
-def cpu_baseline(x_fb, foot, contact, n_sample):
-    """Oracle (CPU port of REF:187-304) on the first n_sample instances over all host cores."""
+def cpu_baseline(s, h, dt, n_sample):
+    """Reference-style CPU path on the first n_sample instances: single-core latency (this process, one
+    BLAS thread) and all-core rate (one process per core, pool start-up and imports excluded)."""
     import multiprocessing as mp
+    import numpy as np
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, MAX_CPU_WORKERS))      # the GPU box grants a 16-CPU share per GPU
-    args = [(x_fb[i].astype(float), foot[i].astype(float), contact[i]) for i in range(n_sample)]
-    t0 = time.perf_counter()
-    with mp.get_context("spawn").Pool(cores) as pool:
-        out = pool.map(_oracle_one, args)
-    wall = time.perf_counter() - t0
-    ctrl = np.stack([o[0] for o in out])
-    per = float(np.mean([o[1] for o in out]))
-    return ctrl, dict(value=n_sample / wall, unit="solves/s", cores=cores, kind="port",
-                      sample=f"{n_sample} instances of the same batch, oracle/bmpc_oracle.solve_mpc (fp64 NumPy "
-                             f"restatement of the reference + IPM/polish), 1 process per core; "
-                             f"{per * 1e3:.0f} ms per solve per core, pool start-up included in the rate")
+
+    def arg(i, full):
+        # a time in the middle of schedule step `phase`, so that int(t // dt) % h (REF:99-100) gives it back
+        return (s["x_fb"][i].astype(float), (float(s["phase"][i]) + 0.5) * dt, s["foot"][i].astype(float), s["contact"][i],
+                s["x_cmd"][i] if s.get("use_x_cmd") else None, None if s["mu"] is None else s["mu"][i],
+                h, s["half"], full)
+
+    _cpu_init()
+    n1 = min(8, n_sample)
+    _cpu_one(arg(0, False))                                             # warm
+    single = [_cpu_one(arg(i, False)) for i in range(n1)]
+    asm_ms = 1e3 * float(np.mean([o[1] for o in single]))
+    sol_ms = 1e3 * float(np.mean([o[2] for o in single]))
+    with mp.get_context("spawn").Pool(cores, initializer=_cpu_init) as pool:
+        pool.map(_cpu_one, [arg(i % n_sample, False) for i in range(2 * cores)])      # start-up, imports
+        t0 = time.perf_counter()
+        out = pool.map(_cpu_one, [arg(i, False) for i in range(n_sample)])
+        wall = time.perf_counter() - t0
+        nfull = min(n_sample, 4 * cores)
+        t0 = time.perf_counter()
+        outf = pool.map(_cpu_one, [arg(i, True) for i in range(nfull)])
+        wallf = time.perf_counter() - t0
+    ctrl_full = np.stack([o[0] for o in outf])
+    ctrl_plain = np.stack([o[0] for o in out])
+    cb = dict(value=n_sample / wall, unit="solves/s", cores=cores, kind="port",
+              single_core_ms={"assembly": asm_ms, "solve": sol_ms, "total": asm_ms + sol_ms},
+              sample=f"{n_sample} instances of the same batch; per instance the reference-style dense assembly "
+                     f"(oracle.build_sparse_qp, REF:203-286) + a plain fp64 Mehrotra interior-point solve without "
+                     f"polish (what REF:297 asks cvxopt for; cvxopt itself is absent from the image); one process "
+                     f"per core, one BLAS thread each, pool start-up and imports excluded; single-core latency "
+                     f"from {n1} instances in this process",
+              oracle_with_polish={"value": nfull / wallf, "unit": "solves/s", "instances": nfull,
+                                  "note": "oracle.solve_mpc as the parity tests use it (IPM + active-set polish + certificate)"})
+    return ctrl_full, ctrl_plain, cb
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="instances for the CPU baseline (0 = skip)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--share-device", action="store_true",
-                    help="rehearsal only: every rank uses cuda:0 (1-GPU box, use with --backend gloo)")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -110,8 +220,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     dev_index = 0 if args.share_device else local_rank
@@ -126,26 +235,77 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import sharding
+    from biped_mpc_py_amd.synth import CONFIGS, synth_batch
 
-    B = args.batch
+    cfg = CONFIGS[args.config]
+    h = cfg["h"]
+    strong = args.scaling == "strong"
     mpc = bm.MPC()
-    cp = bm.pack_params(mpc, bm.Biped())
+    mpc.h = h
+    if strong:
+        total = args.total or 65536
+        s = synth_batch(total, h, cfg["seed"], gait=cfg["gait"], **cfg["kw"])       # ONE global batch
+        lo, hi = sharding.shard_bounds(total, rank, world)
+    else:
+        B0 = args.batch or 4096
+        total = world * B0
+        s = synth_batch(B0, h, cfg["seed"] + 1000 * rank, gait=cfg["gait"], **cfg["kw"])
+        lo, hi = 0, B0
+    B = hi - lo
+    use_x_cmd = bool(cfg["kw"].get("vx_cmd"))
+    s["use_x_cmd"] = use_x_cmd
+    cp = bm.pack_params(mpc, bm.Biped(), half=s["half"])
     if world > 1:                                   # C0: one parameter block for every rank
-        bm.sharding.broadcast_params(cp, src=0, device=coll_dev)
-    solver = bm.BatchSolver(cparams=cp, device=dev_index, max_batch=B)
-    x_fb, foot, contact, phase = synth(B, H, seed=1 + 1000 * rank)   # seed 1 = config 2
-    t_x, t_f = torch.from_numpy(x_fb).to(dev), torch.from_numpy(foot).to(dev)
-    t_c, t_p = torch.from_numpy(contact).to(dev), torch.from_numpy(phase).to(dev)
-    o_u = torch.empty((B, H, 12), dtype=torch.float32, device=dev)
-    o_s = torch.empty((B, H, 13), dtype=torch.float32, device=dev)
+        sharding.broadcast_params(cp, src=0, device=coll_dev)
+    solver = bm.BatchSolver(cparams=cp, device=dev_index, max_batch=max(B, total if (strong and rank == 0) else B))
+
+    def dev_inputs(a, b):
+        t = dict(x_fb=torch.from_numpy(s["x_fb"][a:b].astype(np.float32)).to(dev),
+                 foot=torch.from_numpy(s["foot"][a:b].astype(np.float32)).to(dev),
+                 contact=torch.from_numpy(np.ascontiguousarray(s["contact"][a:b])).to(dev),
+                 phase=torch.from_numpy(np.ascontiguousarray(s["phase"][a:b])).to(dev),
+                 x_cmd=torch.from_numpy(s["x_cmd"][a:b].astype(np.float32)).to(dev) if use_x_cmd else None,
+                 mu=None if s["mu"] is None else torch.from_numpy(s["mu"][a:b].astype(np.float32)).to(dev))
+        return t
+
+    tin = dev_inputs(lo, hi)
+    o_u = torch.empty((B, h, 12), dtype=torch.float32, device=dev)
+    o_s = torch.empty((B, h, 13), dtype=torch.float32, device=dev)
     o_it = torch.empty(B, dtype=torch.int32, device=dev)
     o_st = torch.empty(B, dtype=torch.int32, device=dev)
     o_nf = torch.empty(B, dtype=torch.int32, device=dev)
     o_rs = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    gather = world > 1 and not args.no_gather
+    per = -(-total // world)                        # padded shard length of the all_gather
+    if gather:
+        g_in = o_u if B == per else torch.zeros((per, h, 12), dtype=torch.float32, device=dev)
+        g_in_c = g_in if args.backend == "nccl" else torch.zeros((per, h, 12), dtype=torch.float32)
+        g_out = torch.empty((world * per, h, 12), dtype=torch.float32, device=coll_dev)
+        if strong:
+            pbuf = torch.from_numpy(np.frombuffer(bytes(cp), dtype=np.uint8).copy()).to(coll_dev)
 
-    def step():
-        solver.solve_device(t_x, t_f, t_c, t_p, controls=o_u, states=o_s, iters=o_it, residuals=o_rs,
-                            status=o_st, nfactor=o_nf)
+    kev = []
+
+    def step(timed):
+        if gather and strong:                       # C0 inside the step: the block every rank solves with
+            dist.broadcast(pbuf, src=0)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        solver.solve_device(tin["x_fb"], tin["foot"], tin["contact"], tin["phase"], x_cmd=tin["x_cmd"], mu=tin["mu"],
+                            controls=o_u, states=o_s, iters=o_it, residuals=o_rs, status=o_st, nfactor=o_nf)
+        if timed:
+            e1.record()
+            kev.append((e0, e1))
+        if gather:                                  # C2: every rank receives all controls
+            if g_in is not o_u:
+                g_in[:B].copy_(o_u)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(g_out, g_in)
+            else:                                   # rehearsal backend: collectives on host tensors
+                g_in_c.copy_(g_in)
+                dist.all_gather_into_tensor(g_out, g_in_c)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -153,73 +313,124 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # the kernel is launched on torch's CURRENT stream; make that a real (non-null) stream so that
-    # the events below are recorded on exactly the stream the kernel runs on
+    # the kernel is launched on torch's CURRENT stream; a real (non-null) stream, so that the events are
+    # recorded on exactly the stream the kernel runs on
     launch_stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(launch_stream):
         for _ in range(args.warmup):
-            step()
+            step(False)
         fence()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()
         for _ in range(args.steps):
-            step()
-        ev1.record()
+            step(True)
         fence()
         elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration over the timed region
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))     # average launch duration, timed region
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
 
     iters = o_it.cpu().numpy()
     nfac = o_nf.cpu().numpy()
     status = o_st.cpu().numpy()
+    line = None
     if rank == 0:
-        fl, parts = flops_per_solve(H, float(iters.mean()), float(nfac.mean()))
-        achieved = fl * B / (kernel_ms * 1e-3) / 1e12
-        traffic = None                     # HBM bytes per launch from the committed PMC passes (profiles/)
+        fl_s = flops_survey(h, float(iters.mean()))
+        fl_r, parts = flops_run(h, float(iters.mean()), float(nfac.mean()))
+        ach = fl_s * B / (kernel_ms * 1e-3) / 1e12
+        ach_min = fl_r * B / (kernel_ms * 1e-3) / 1e12
+        traffic, traffic_source = None, None          # HBM bytes per launch: PMC passes need rocprofv3 (profiles/)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
-                pm = json.load(fh)
-            if pm.get("batch") == B:
-                traffic = pm["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
+            with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
+                for pm in json.load(fh):
+                    if pm.get("batch") == B and pm.get("config") == args.config:
+                        traffic = pm["traffic_bytes_per_launch"]
+                        traffic_source = "replayed from " + pm.get("source", "profiles/pmc_summary.json") + \
+                                         " (rocprofv3 --pmc passes of this command; not measured in this run)"
+        except (OSError, ValueError, KeyError, TypeError):
             pass
+        what = (f"one batch of {total} sharded over {world} GPU(s)" if strong else f"batch={B} per GPU")
         line = {
-            "metric": "MPC QP solves/sec (N=10, 2-contact)",
-            "value": world * B * args.steps / elapsed,
+            "metric": "MPC QP solves/sec (N=10, 2-contact)" if h == 10 else f"MPC QP solves/sec (N={h})",
+            "value": total * args.steps / elapsed,
             "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=4096 randomised CoM/stance states per GPU, horizon 10, "
-                                   "double support, inputs resident in HBM",
-                       "batch_per_gpu": B, "horizon": H, "residual_dtype": "f64",
+            "config": {"workload": f"{cfg['label']}; {what}, inputs resident in HBM",
+                       "baseline_config": args.config, "batch_per_gpu": B, "total": total, "horizon": h,
+                       "residual_dtype": "f64", "collectives_in_step": (["broadcast(params)"] if gather and strong else []) +
+                       (["all_gather(controls)"] if gather else []),
                        "mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
                        "mean_factorisations": float(nfac.mean()),
                        "not_converged": int((status != 0).sum())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "bmpc::solve_kernel<10,double>", "kernel_ms": kernel_ms,
-                         "flops_per_solve": fl, "flops_parts": parts,
-                         "hbm_algorithmic_bytes_per_solve": 4 * (12 + 6 + 1) + 2 * H + 4 * 25 * H + 20},
+            "roofline": {"bound": "valu_f32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_TFLOPS,
+                         "achieved_minimal": ach_min, "frac_minimal": ach_min / PEAK_FP32_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": f"bmpc::solve_kernel<{h},double>", "kernel_ms": kernel_ms,
+                         "flops_per_solve": fl_s, "flops_per_solve_minimal": fl_r, "flops_parts_minimal": parts,
+                         "note": "compute-bound on the packed-f32 vector pipe (no MFMA in this kernel: the f32 matrix "
+                                 "rate of CDNA4 equals the vector rate); `achieved` uses SURVEY 8(d)'s dense "
+                                 "condensed-ADMM flop formula, `achieved_minimal` the flops of the algorithm that runs",
+                         "hbm_algorithmic_bytes_per_solve": hbm_bytes_per_solve(h, use_x_cmd, s["mu"] is not None)},
         }
+    # strong scaling: the gathered controls against the single-GPU solve of the whole batch, bit for bit
+    if gather and strong:
+        fence()
+        if rank == 0:
+            tall = dev_inputs(0, total)
+            u1 = torch.empty((total, h, 12), dtype=torch.float32, device=dev)
+            solver.solve_device(tall["x_fb"], tall["foot"], tall["contact"], tall["phase"], x_cmd=tall["x_cmd"],
+                                mu=tall["mu"], controls=u1)
+            torch.cuda.synchronize(dev)
+            got = torch.cat([g_out[r * per:r * per + (sharding.shard_bounds(total, r, world)[1] -
+                                                     sharding.shard_bounds(total, r, world)[0])] for r in range(world)])
+            same = bool(torch.equal(got.to(dev), u1))
+            line["config"]["gather_check"] = ("gathered controls bit-identical to the N=1 solve of the whole batch"
+                                              if same else "MISMATCH against the N=1 solve")
+            if not same:
+                raise SystemExit("gathered controls differ from the single-GPU result")
+    if rank == 0:
+        # whole-batch wall clock through the host-pointer entry (H2D + kernel + D2H, fp32 over PCIe)
+        xs = [s[k][lo:hi] for k in ("x_fb", "foot", "contact", "phase")]
+        kw = dict(x_cmd=s["x_cmd"][lo:hi] if use_x_cmd else None, mu=None if s["mu"] is None else s["mu"][lo:hi])
+        solver.solve(*xs, **kw)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solver.solve(*xs, **kw)
+        line["value_incl_pcie"] = {"value": B * reps / (time.perf_counter() - t0), "unit": "solves/s", "n_gpus": 1,
+                                   "what": "bmpc_solve_batch on host arrays: H2D + kernel + D2H + fp64 conversion, one GPU"}
         if world == 1 and args.cpu_sample > 0:
             n = min(args.cpu_sample, B)
-            ref, cb = cpu_baseline(x_fb, foot, contact, n)
-            got = o_u.cpu().numpy()[:n].astype(np.float64)
-            rel = np.abs(got - ref).reshape(n, -1).max(1) / np.maximum(1.0, np.abs(ref).reshape(n, -1).max(1))
+            ref_full, ref_plain, cb = cpu_baseline(s, h, mpc.dt, n)
+            got = o_u.cpu().numpy().astype(np.float64)
+
+            def rel(a, b):
+                k = len(b)
+                return np.abs(a[:k] - b).reshape(k, -1).max(1) / np.maximum(1.0, np.abs(b).reshape(k, -1).max(1))
+            r_full, r_plain = rel(got, ref_full), rel(got, ref_plain)
             line["cpu_baseline"] = cb
-            line["parity"] = {"max_rel_err_vs_oracle": float(rel.max()), "max_abs_err": float(np.abs(got - ref).max()),
-                              "instances": n, "tolerance": 1e-4}
+            line["parity"] = {"max_rel_err_vs_oracle": float(r_full.max()), "instances": int(len(r_full)),
+                              "p99.9_rel_err_vs_plain_ipm": float(np.quantile(r_plain, 0.999)),
+                              "max_rel_err_vs_plain_ipm": float(r_plain.max()), "instances_plain_ipm": int(len(r_plain)),
+                              "max_abs_err": float(np.abs(got[:len(ref_full)] - ref_full).max()),
+                              "u0_max_rel_err": float(rel(got[:, :1], ref_full[:, :1]).max()), "tolerance": 1e-4}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, argv))      # no torch, no HIP in this process
+    run_rank(args)
 
 
 if __name__ == "__main__":

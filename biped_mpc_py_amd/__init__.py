@@ -6,10 +6,11 @@ does not load the shared library; the first solver call does, and raises if it i
 """
 from .params import MPC, Biped, pack_params                                  # noqa: F401
 from .api import (BatchSolver, solve_mpc, solve_mpc_batch, get_contact_sequence,   # noqa: F401
-                  phase_index, lowLevelControl, getFootPositionWorld)
+                  phase_index, lowLevelControl, getFootPositionWorld, SolverStatusWarning,
+                  close_cached_solvers)
 from . import sharding                                                        # noqa: F401
 from ._lib import BmpcError                                                   # noqa: F401
 
 __all__ = ["MPC", "Biped", "pack_params", "BatchSolver", "solve_mpc", "solve_mpc_batch",
            "get_contact_sequence", "phase_index", "lowLevelControl", "getFootPositionWorld", "sharding",
-           "BmpcError"]
+           "BmpcError", "SolverStatusWarning", "close_cached_solvers"]

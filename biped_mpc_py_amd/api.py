@@ -56,6 +56,11 @@ class BatchSolver:
         self._h = C.c_void_p()
         _lib.check(self._lib.bmpc_create(C.byref(self._h), C.byref(self.cparams), self.device, self.max_batch))
 
+    def set_params(self, cparams):
+        """Replace the parameter block of this handle (same horizon): `bmpc_set_params`."""
+        _lib.check(self._lib.bmpc_set_params(self._h, C.byref(cparams)))
+        self.cparams = cparams
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.bmpc_destroy(self._h)
@@ -119,7 +124,9 @@ class BatchSolver:
                      iters=None, residuals=None, status=None, nfactor=None, stream=None):
         """Inputs/outputs are CUDA(HIP) torch tensors on this solver's device (fp32 / uint8 / int32,
         contiguous).  Asynchronous on `stream` (default: torch's current stream).  Returns the
-        output tensors; nothing crosses PCIe."""
+        output tensors; nothing crosses PCIe.  `stream` is a raw hipStream_t value; torch's default stream
+        is HIP's null stream (value 0) and is passed on as such, so the launch is ordered against the
+        surrounding torch work like any torch kernel."""
         import torch
         B = x_fb.shape[0]
         h = self.h
@@ -233,24 +240,58 @@ class BatchSolver:
         _lib.check(self._lib.bmpc_synchronize(self._h))
 
 
-_SOLVERS = {}
+class SolverStatusWarning(RuntimeWarning):
+    """Some instances stopped at the iteration cap (status 1): their controls are the last iterate."""
+
+
+def _check_status(info, where):
+    """The reference never looks at its solver's status (REF:297-300); a drop-in that silently hands a
+    non-converged or non-finite iterate to `lowLevelControl` would be worse than that.  Status 2 (NaN/Inf
+    iterate: non-finite inputs) is an error, status 1 (iteration cap) a warning.  Callers who want to
+    handle it themselves pass `return_info=True`."""
+    import warnings
+    status = info["status"]
+    nbad = int((status == 2).sum())
+    if nbad:
+        raise FloatingPointError(f"{where}: {nbad} of {status.size} instances produced a NaN/Inf iterate "
+                                 f"(status 2; first at index {int(np.flatnonzero(status == 2)[0])})")
+    ncap = int((status == 1).sum())
+    if ncap:
+        warnings.warn(f"{where}: {ncap} of {status.size} instances stopped at the iteration cap "
+                      f"(status 1); their controls are the last iterate", SolverStatusWarning, stacklevel=3)
+
+
+_SOLVERS = {}          # (h, device) -> BatchSolver: ONE handle per horizon and device, whatever the parameters
 
 
 def _cached_solver(mpc, biped, half, device, solver_options):
+    """The drop-in wrappers keep one handle per (horizon, device) and push a changed parameter block
+    through `bmpc_set_params`; a control loop that varies `mpc.x_cmd`, `Q`, `mu` ... from step to step
+    therefore never creates a second handle (stream + events + staging buffers)."""
     cp = pack_params(mpc, biped, half, solver_options)
-    key = (params_key(cp), int(device))
+    key = (int(cp.h), int(device))
     s = _SOLVERS.get(key)
     if s is None:
         s = BatchSolver(cparams=cp, device=device)
         _SOLVERS[key] = s
+    elif params_key(cp) != params_key(s.cparams):
+        s.set_params(cp)
     return s
+
+
+def close_cached_solvers():
+    """Destroy the handles the drop-in wrappers keep (tests; orderly shutdown)."""
+    for s in _SOLVERS.values():
+        s.close()
+    _SOLVERS.clear()
 
 
 def solve_mpc_batch(x_fb, t, foot, contact, mpc=None, biped=None, x_cmd=None, mu=None, phase=None, half=None,
                     device=0, solver_options=None, return_info=False):
     """B instances of REF:187 `solve_mpc`.  x_fb (B,12), t (B,) seconds [or phase (B,) directly],
     foot (B,6), contact (B,h,2); optional per-instance x_cmd (B,12) and mu (B,h,2).
-    Returns states (B,h,13), controls (B,h,12) [, info]."""
+    Returns states (B,h,13), controls (B,h,12) [, info].  Without `return_info` a NaN/Inf instance raises
+    FloatingPointError and instances stopped at the iteration cap raise a SolverStatusWarning."""
     from .params import MPC
     mpc = mpc if mpc is not None else MPC()
     solver = _cached_solver(mpc, biped, half, device, solver_options)
@@ -260,6 +301,7 @@ def solve_mpc_batch(x_fb, t, foot, contact, mpc=None, biped=None, x_cmd=None, mu
     states, controls, info = solver.solve(x_fb, foot, contact, phase, x_cmd=x_cmd, mu=mu)
     if return_info:
         return states, controls, info
+    _check_status(info, "solve_mpc")
     return states, controls
 
 

@@ -136,6 +136,12 @@ int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const ui
   }
 }
 
+// NULL is HIP's null (legacy default) stream, like every hip* call; BMPC_STREAM_OWN the handle's own stream
+hipStream_t pick_stream(bmpc_handle h, void* stream) {
+  if (stream == BMPC_STREAM_OWN) return h->stream;
+  return static_cast<hipStream_t>(stream);
+}
+
 int check_common(bmpc_handle h, int B, const void* x_fb, const void* foot, const void* contact, const void* phase,
                  const void* controls) {
   if (!h) return fail(BMPC_ERR_INVALID, "null handle");
@@ -248,7 +254,7 @@ int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float
   if (rc != BMPC_OK) return rc;
   if (B == 0) return BMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t st = pick_stream(h, stream);
   bmpc::DebugOut dbg = {nullptr, nullptr, nullptr, nullptr, h->prof_dev, 0};
   HIP_TRY(hipEventRecord(h->ev0, st));
   rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st);
@@ -349,7 +355,7 @@ int bmpc_foot_position_world_device(bmpc_handle h, int B, const float* x_fb, con
   if (B == 0) return BMPC_OK;
   if (!x_fb || !q || !pf_w) return fail(BMPC_ERR_INVALID, "null pointer");
   HIP_TRY(hipSetDevice(h->device));
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t st = pick_stream(h, stream);
   hipLaunchKernelGGL(bmpc::foot_world_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ll_params(h->params), B, x_fb, q, pf_w);
   HIP_TRY(hipGetLastError());
   return BMPC_OK;
@@ -381,7 +387,7 @@ int bmpc_low_level_control_device(bmpc_handle h, int B, const float* x_fb, const
   if (B == 0) return BMPC_OK;
   if (!x_fb || !t || !pf_w || !q || !qd || !contact0 || !u0 || !tau) return fail(BMPC_ERR_INVALID, "null pointer");
   HIP_TRY(hipSetDevice(h->device));
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t st = pick_stream(h, stream);
   hipLaunchKernelGGL(bmpc::lowlevel_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ll_params(h->params), B, x_fb, t,
                      pf_w, q, qd, contact0, u0, tau);
   HIP_TRY(hipGetLastError());
@@ -446,7 +452,7 @@ int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bm
   int rc = gait_params(h, gait, &G);
   if (rc != BMPC_OK) return rc;
   HIP_TRY(hipSetDevice(h->device));
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t st = pick_stream(h, stream);
   hipLaunchKernelGGL(bmpc::gait_kernel, dim3((B + 255) / 256), dim3(256), 0, st, G, B, t, phase, contact);
   HIP_TRY(hipGetLastError());
   return BMPC_OK;

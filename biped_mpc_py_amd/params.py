@@ -49,8 +49,10 @@ SOLVER_FIELDS = ("rho", "rho_eq_scale", "rho_lo", "rho_hi_f", "rho_hi_m", "kappa
 
 
 def pack_params(mpc=None, biped=None, half=None, solver_options=None):
-    """Build a `bmpc_params` from reference-style objects.  `half` defaults to the reference's
-    hard-coded 5 (REF:101-105) unless `mpc.half` exists."""
+    """Build a `bmpc_params` from reference-style objects.  `half` (gait half period of the reference-foot
+    generator) defaults to `mpc.half` if that exists, else to what `bmpc_default_params` chose for this
+    horizon: the reference's hard-coded 5 at h = 10 (REF:101-105), h / 2 otherwise -- the half period the
+    periodic contact table of `get_contact_sequence(t, mpc, half=...)` has for that horizon."""
     mpc = mpc if mpc is not None else MPC()
     biped = biped if biped is not None else Biped()
     lib = _lib.load()
@@ -58,7 +60,8 @@ def pack_params(mpc=None, biped=None, half=None, solver_options=None):
     h = int(mpc.h)
     _lib.check(lib.bmpc_default_params(cp, h))       # solver defaults; physical fields overwritten below
     cp.h = h
-    cp.half = int(half if half is not None else getattr(mpc, "half", 5))
+    if half is not None or hasattr(mpc, "half"):
+        cp.half = int(half if half is not None else mpc.half)
     cp.dt = float(mpc.dt)
     cp.kv = float(mpc.kv)
     x_cmd = np.asarray(mpc.x_cmd, float).reshape(12)

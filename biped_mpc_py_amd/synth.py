@@ -1,0 +1,50 @@
+"""Synthetic randomised CoM / stance inputs of SURVEY.md 8(d): the workload generator that bench.py, the
+tools and the parity tests share (the product never needs it; it lives here so that it ships with the
+package).  `np.random.default_rng(seed)`; the draw order is fixed -- the oracle-solved fixtures under
+tests/golden/tuning were generated from it."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_mu=False):
+    """x_fb: euler ~ U(-0.2, 0.2)^3 rad, pos x, y ~ U(-0.5, 0.5), z ~ U(0.45, 0.60), omega ~ U(-0.5, 0.5)^3,
+    v ~ U(-0.5, 0.5)^2 x U(-0.2, 0.2); foot_i = (x - 0.0195 + U(-0.05, 0.05), y +- (0.089 + U(-0.03, 0.03)), 0)
+    (nominal stance of the reference FK, REF:478-479); x_cmd: REF:26, optionally v_x,cmd ~ U(-0.5, 0.5).
+    gait: "standing" (contact = 1, phase 0), "walking" (alternating single support of half period `half`,
+    phase ~ U{0..h-1}: generalises REF:52-58) or "mixed" (config 4: standing or any walking phase).
+    per_step_mu: mu[k, foot] ~ U(0.3, 0.9) (config 5).  Returns a dict of fp64 / uint8 / int32 arrays."""
+    rng = np.random.default_rng(seed)
+    x_fb = np.concatenate([
+        rng.uniform(-0.2, 0.2, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(0.45, 0.60, (B, 1)),
+        rng.uniform(-0.5, 0.5, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(-0.2, 0.2, (B, 1))], 1)
+    foot = np.zeros((B, 6))
+    for j, sgn in enumerate((1.0, -1.0)):
+        foot[:, 3 * j + 0] = x_fb[:, 3] - 0.0195 + rng.uniform(-0.05, 0.05, B)
+        foot[:, 3 * j + 1] = x_fb[:, 4] + sgn * (0.089 + rng.uniform(-0.03, 0.03, B))
+    half = half or (5 if h == 10 else h // 2)
+    x_cmd = np.tile(np.array([0, 0, 0, 0, 0, 0.55, 0, 0, 0, 0, 0, 0.0]), (B, 1))
+    if vx_cmd:
+        x_cmd[:, 9] = rng.uniform(-0.5, 0.5, B)
+    if gait == "standing":
+        phase = np.zeros(B, np.int32)
+        contact = np.ones((B, h, 2), np.uint8)
+    else:
+        leg0 = (np.arange(4 * half) // half) % 2 == 0
+        table = np.stack([leg0, ~leg0], 1).astype(np.uint8)
+        phase = rng.integers(0, h, B).astype(np.int32)
+        contact = np.stack([table[k:k + h] for k in phase])
+        if gait == "mixed":                      # config 4: standing or any walking phase
+            stand = rng.integers(0, h + 1, B) == 0
+            contact[stand] = 1
+    mu = rng.uniform(0.3, 0.9, (B, h, 2)) if per_step_mu else None
+    return dict(x_fb=x_fb, foot=foot, contact=contact, phase=phase, x_cmd=x_cmd, mu=mu, half=half)
+
+
+# BASELINE.json configs 2-5 as generator arguments (seed = config number - 1)
+CONFIGS = {
+    2: dict(h=10, gait="standing", seed=1, kw=dict(), batch=4096, label="configs[1]: randomised CoM/stance states, horizon 10, double support"),
+    3: dict(h=16, gait="walking", seed=2, kw=dict(vx_cmd=True), batch=4096, label="configs[2]: horizon 16, alternating single support (half period 8), random v_x command"),
+    4: dict(h=10, gait="mixed", seed=3, kw=dict(vx_cmd=True), batch=65536, label="configs[3]: horizon 10, mixed gait schedules (standing or any walking phase)"),
+    5: dict(h=20, gait="walking", seed=4, kw=dict(vx_cmd=True, per_step_mu=True), batch=65536, label="configs[4]: horizon 20, walking (half period 10), per-step per-foot friction"),
+}

@@ -21,7 +21,14 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 3
+#define BMPC_ABI_VERSION 4
+
+/* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
+ * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
+ * launch is ordered after the caller's earlier work on that stream and before its later work, exactly
+ * like a hip* call.  BMPC_STREAM_OWN selects the handle's private (non-blocking) stream, the one the
+ * host-pointer entry points use. */
+#define BMPC_STREAM_OWN ((void*)(intptr_t)-1)
 
 enum bmpc_status {
   BMPC_OK = 0,
@@ -125,7 +132,7 @@ int bmpc_solve_batch(bmpc_handle h, int B,
 
 /*
  * Same, DEVICE pointers (memory of the handle's device), asynchronous on `stream`
- * (a hipStream_t passed as void*; NULL = the handle's own stream).  Nothing is copied.
+ * (see BMPC_STREAM_OWN above for NULL and the handle's own stream).  Nothing is copied.
  * This is the entry the bench times and the one a device-resident control loop uses.
  */
 int bmpc_solve_batch_device(bmpc_handle h, int B,
@@ -158,7 +165,8 @@ int bmpc_debug_assemble(bmpc_handle h, int B,
  *       swingLegControl REF:426-442):
  *       x_fb [B][12], t [B] (seconds, fp64), pf_w [B][6], q [B][10], qd [B][10],
  *       contact0 [B][2] = contact[0, 0:2], u0 [B][12] = controls[0]  ->  tau [B][10]
- * The *_device variants take DEVICE pointers and a stream (NULL = the handle's) and do not synchronise.
+ * The *_device variants take DEVICE pointers and a stream (NULL = the null stream, BMPC_STREAM_OWN = the
+ * handle's) and do not synchronise.
  */
 int bmpc_foot_position_world(bmpc_handle h, int B, const float* x_fb, const float* q, float* pf_w);
 int bmpc_foot_position_world_device(bmpc_handle h, int B, const float* x_fb, const float* q, float* pf_w, void* stream);
@@ -191,8 +199,11 @@ int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bm
  * (default).  Costs a few s_memtime per phase. */
 int bmpc_debug_set_profile(bmpc_handle h, long long* device_buf);
 
-/* Time of the last bmpc_solve_batch* kernel launch on the handle's stream, measured with HIP
- * events around the launch (milliseconds); <0 if none.  Forces a stream synchronise. */
+/* Duration of the LAST bmpc_solve_batch* kernel launch made through this handle, measured with one pair of
+ * HIP events recorded around the launch on the launch's stream (milliseconds); <0 if none.  Waits for
+ * that launch.  A handle owns ONE event pair: with several launches in flight through the same handle
+ * (back-to-back asynchronous calls, or calls on different streams) only the last one is reported, and it
+ * is only meaningful if no other launch of this handle overlapped it. */
 int bmpc_last_kernel_ms(bmpc_handle h, float* ms);
 
 #ifdef __cplusplus

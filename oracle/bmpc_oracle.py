@@ -439,12 +439,13 @@ def _polish(H, g, C, d, u, lam):
     return u, lam, False
 
 
-def solve_qp(P, q, G, hvec, A, b, nx):
+def solve_qp(P, q, G, hvec, A, b, nx, polish=True):
     """Unique minimiser of the reference QP (REF:297 arguments) in fp64.
 
     Steps: condense through the equality block; turn opposing inequality pairs into fixed
     directions (pinned variables, SURVEY H2) and eliminate them; drop rows that became empty;
-    Mehrotra IPM on the strictly feasible remainder; active-set polish.  Returns
+    Mehrotra IPM on the strictly feasible remainder; active-set polish (`polish=False` stops after the
+    IPM: the plain fp64 solve bench.py times as the reference-style CPU baseline).  Returns
     (z, lam (rows of G), nu (rows of A), info) with info['kkt'] the certificate residuals.
     """
     P = np.asarray(P, float)
@@ -474,7 +475,9 @@ def solve_qp(P, q, G, hvec, A, b, nx):
     Hr = Hc[np.ix_(free, free)]
     gr = gc[free] + Hc[np.ix_(free, fixed)] @ uval[fixed]
     ur, lr = _ipm(Hr, gr, Cr, dr)
-    ur, lr, polished = _polish(Hr, gr, Cr, dr, ur, lr)
+    polished = False
+    if polish:
+        ur, lr, polished = _polish(Hr, gr, Cr, dr, ur, lr)
     U = uval.copy()
     U[free] = ur
     X = s + Bqp @ U

@@ -353,3 +353,186 @@ def test_rare_active_set_cycles_are_damped(h, seed, kw):
     sol.close()
     assert int((info["status"] != 0).sum()) == 0
     assert int(info["iters"].max()) < 300 and not np.isnan(u).any()
+
+
+def _oracle_controls(s, idx, h, mpc_mod=None, biped_mod=None):
+    """Oracle optimum for instances `idx` of a synth_batch dict, on the float32-rounded inputs the GPU sees."""
+    from oracle import bmpc_oracle as orc
+    out = []
+    for i in idx:
+        m, b = orc.MPC(), orc.Biped()
+        m.h = h
+        m.x_cmd = s["x_cmd"][i]
+        if mpc_mod:
+            mpc_mod(m)
+        if biped_mod:
+            biped_mod(b)
+        mu_i = None if s["mu"] is None else s["mu"][i].astype(np.float32).astype(float)
+        _, ct = orc.solve_mpc(s["x_fb"][i].astype(np.float32).astype(float), (s["phase"][i] + 0.5) * m.dt,
+                              s["foot"][i].astype(np.float32).astype(float), m, b, s["contact"][i], half=s["half"], mu_steps=mu_i)
+        out.append(ct)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("h,gait,seed,kw", [
+    (10, "mixed", 501, dict(vx_cmd=True)), (10, "standing", 502, {}),
+    (16, "walking", 503, dict(vx_cmd=True)), (20, "walking", 504, dict(vx_cmd=True, per_step_mu=True))])
+def test_hardest_instances_vs_oracle(h, gait, seed, kw):
+    """The HARDEST instances (most iterations) of a 16384 batch of every config shape against the fp64 oracle."""
+    import biped_mpc_py_amd as bm
+    B, n = 16384, 8
+    s = util.synth_batch(B, h, seed, gait=gait, **kw)
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
+    sol.close()
+    assert int((info["status"] != 0).sum()) == 0
+    idx = np.argsort(-info["iters"], kind="stable")[:n]
+    ref = _oracle_controls(s, idx, h)
+    rel = util.rel_err(u[idx], ref)
+    print("h=%d %s: hardest %d of %d (iterations %d..%d): max rel err %.2e" % (h, gait, n, B, info["iters"][idx].min(),
+                                                                             info["iters"][idx].max(), rel.max()))
+    assert rel.max() <= util.REL_TOL
+
+
+@pytest.mark.parametrize("what", ["Q_x10", "Q_div10", "R_x10", "R_div10", "f_max_150", "R_mixed"])
+def test_non_default_weights_and_bounds(what):
+    """REF:278-286 / REF:45-48 with other numbers than the reference's defaults: the cost weights set the
+    conditioning the penalty schedule was tuned around, so they are varied by a decade either way, and the
+    force cap is lowered until it binds in double support.  Against the oracle with the same parameters."""
+    import biped_mpc_py_amd as bm
+    B = 12
+    mods = {
+        "Q_x10": (lambda m: setattr(m, "Q", np.asarray(m.Q, float) * 10.0), None),
+        "Q_div10": (lambda m: setattr(m, "Q", np.asarray(m.Q, float) / 10.0), None),
+        "R_x10": (lambda m: setattr(m, "R", np.asarray(m.R, float) * 10.0), None),
+        "R_div10": (lambda m: setattr(m, "R", np.asarray(m.R, float) / 10.0), None),
+        "R_mixed": (lambda m: setattr(m, "R", np.asarray(m.R, float) * np.array([1, 3, 10, 1, 3, 10, 30, 1, 3, 30, 1, 3.0])), None),
+        "f_max_150": (None, lambda b: setattr(b, "f_max", np.array([[150.0], [150.0], [55.0]]))),
+    }
+    mpc_mod, biped_mod = mods[what]
+    for gait, seed, kw in (("standing", 41, {}), ("walking", 42, dict(vx_cmd=True))):
+        s = util.synth_batch(B, 10, seed, gait=gait, **kw)
+        mpc, biped = bm.MPC(), bm.Biped()
+        if mpc_mod:
+            mpc_mod(mpc)
+        if biped_mod:
+            biped_mod(biped)
+        sol = bm.BatchSolver(mpc=mpc, biped=biped, half=s["half"], max_batch=B)
+        _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], want_states=False)
+        sol.close()
+        ref = _oracle_controls(s, range(B), 10, mpc_mod, biped_mod)
+        rel = util.rel_err(u, ref)
+        print(what, gait, "err max %.2e iters mean %.1f max %d nfac %.1f" % (rel.max(), info["iters"].mean(), info["iters"].max(),
+                                                                           info["nfactor"].mean()))
+        assert int((info["status"] != 0).sum()) == 0
+        assert rel.max() <= util.REL_TOL
+        if what == "f_max_150" and gait == "standing":
+            assert np.abs(ref[:, :, 2] - 55.0).min() < 1e-6          # the lowered cap really binds
+
+
+def test_solve_device_is_ordered_on_the_default_stream():
+    """`solve_device` without a stream runs on torch's current stream.  On the DEFAULT stream that is HIP's null
+    stream (cuda_stream == 0): the launch must be ordered after a long-running torch producer of x_fb on that
+    stream and before the torch consumer of the controls (it used to go to the handle's own
+    non-blocking stream, unordered against both)."""
+    import torch
+    import biped_mpc_py_amd as bm
+    B, h = 512, 10
+    dev = torch.device("cuda", 0)
+    s = util.synth_batch(B, h, 7)
+    sol = bm.BatchSolver(max_batch=B)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0
+    x_ok = torch.from_numpy(s["x_fb"].astype(np.float32)).to(dev)
+    foot = torch.from_numpy(s["foot"].astype(np.float32)).to(dev)
+    contact = torch.from_numpy(s["contact"]).to(dev)
+    phase = torch.from_numpy(s["phase"]).to(dev)
+    want, _ = sol.solve_device(x_ok, foot, contact, phase)
+    torch.cuda.synchronize()
+    want = want.clone()
+    big = torch.randn(8192, 8192, device=dev)
+    for _ in range(3):
+        x_in = torch.full((B, 12), float("nan"), device=dev)        # a solve that ran too early would see NaNs
+        acc = big
+        for _ in range(6):                                           # ~tens of ms of work queued on the null stream
+            acc = acc @ big * 1e-4
+        x_in.copy_(x_ok + 0.0 * acc[:B, :12].nan_to_num(0.0, 0.0, 0.0))
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        got, _ = sol.solve_device(x_in, foot, contact, phase, status=status)
+        out = got.clone()                                            # consumer on the same stream
+        got.zero_()                                                  # and a later writer: must come after the kernel's stores
+        torch.cuda.synchronize()
+        assert int((status != 0).sum()) == 0
+        assert torch.equal(out, want)
+    sol.close()
+
+
+def test_dropin_reuses_one_handle_and_reports_status():
+    """The drop-in wrappers keep ONE handle per (horizon, device) however often the command changes (ADVICE r1:
+    one handle per distinct parameter block leaked streams and buffers), answers follow the changed
+    parameters, and a non-converged / non-finite result is not handed back silently."""
+    import warnings
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import api
+    from oracle import bmpc_oracle as orc
+    d = util.load("known_standing")
+    api.close_cached_solvers()
+    mpc, biped = bm.MPC(), bm.Biped()
+    for k in range(6):
+        mpc.x_cmd = np.array([0, 0, 0, 0, 0, 0.50 + 0.01 * k, 0, 0, 0, 0.05 * k, 0, 0], float)
+        _, ctrl = bm.solve_mpc(d["x_fb"], float(d["t"]), d["foot"], mpc, biped, d["contact"])
+        om = orc.MPC()
+        om.x_cmd = mpc.x_cmd
+        _, ref = orc.solve_mpc(np.asarray(d["x_fb"], np.float32).astype(float), float(d["t"]),
+                               np.asarray(d["foot"], np.float32).astype(float), om, orc.Biped(), d["contact"])
+        assert util.rel_err(ctrl[None], ref[None]).max() <= util.REL_TOL
+        assert len(api._SOLVERS) == 1
+    # iteration cap -> warning, NaN input -> error; return_info hands the status over instead
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        bm.solve_mpc(d["x_fb"], float(d["t"]), d["foot"], mpc, biped, d["contact"], solver_options=dict(max_iter=5))
+    assert any(issubclass(x.category, bm.SolverStatusWarning) for x in w)
+    bad = np.array(d["x_fb"], float).copy()
+    bad[4] = np.nan
+    with pytest.raises(FloatingPointError):
+        bm.solve_mpc(bad, float(d["t"]), d["foot"], mpc, biped, d["contact"])
+    _, _, info = bm.solve_mpc_batch(bad[None], [float(d["t"])], np.asarray(d["foot"], float)[None], d["contact"][None, :10],
+                                    mpc=mpc, biped=biped, return_info=True)
+    assert info["status"][0] == 2
+    assert len(api._SOLVERS) == 1
+    api.close_cached_solvers()
+
+
+def test_default_half_follows_horizon_on_device():
+    """h = 16 without an explicit `half`: the reference-foot generator must use the half period of the contact
+    table (8), not the reference's hard-coded 5."""
+    import biped_mpc_py_amd as bm
+    d = util.load("cfg3_trot_h16")
+    mpc = bm.MPC()
+    mpc.h = 16
+    sol = bm.BatchSolver(mpc=mpc, max_batch=len(d["x_fb"]))          # no half
+    _, u, info = sol.solve(d["x_fb"], d["foot"], d["contact"], util.phases(d["t"], mpc.dt, 16), x_cmd=d["x_cmd"], want_states=False)
+    sol.close()
+    assert util.rel_err(u, d["controls"]).max() <= util.REL_TOL
+
+
+def test_bench_two_ranks_strong_scaling():
+    """The N > 1 path end to end with the real kernel: `python bench.py --gpus 2` started bare (it spawns its
+    ranks itself), config-4 strong scaling of ONE seeded batch, parameter broadcast + all_gather of the controls
+    inside the timed region, gathered result bit-identical to the single-GPU solve.  Both ranks share this box's
+    one GPU, so the collectives run over gloo here (RCCL refuses two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--config", "4", "--scaling", "strong", "--total", "4099", "--backend", "gloo", "--share-device"],
+                       env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([x for x in p.stdout.decode().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["total"] == 4099
+    assert "bit-identical" in line["config"]["gather_check"]
+    assert line["config"]["not_converged"] == 0

@@ -61,3 +61,47 @@ def test_synthetic_generator_is_deterministic():
     b = util.synth_batch(8, 10, 5, gait="mixed", vx_cmd=True)
     assert all(np.array_equal(a[k], b[k]) for k in ("x_fb", "foot", "contact", "phase", "x_cmd"))
     assert set(np.unique(a["contact"])) <= {0, 1}
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` with no launcher environment spawns its ranks itself (the parent never
+    touches torch or HIP).  Without a GPU every rank exits with "needs a GPU": the parent must come back
+    with a non-zero code and no JSON line instead of hanging in a collective."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():                        # on a GPU box the second rank has no device of its own
+        assert p.returncode != 0 or b'"n_gpus": 2' in p.stdout
+    else:
+        assert p.returncode != 0 and b"{" not in p.stdout
+        assert b"needs a GPU" in p.stderr
+    assert time.time() - t0 < 300
+
+
+def test_bench_flop_counts_and_bytes():
+    import bench
+    # SURVEY 8(d): h = 10 -> F_setup = 2.712 MFLOP, F_iter = 35.2 kFLOP; h = 20 -> 20.67 MFLOP, 128.0 kFLOP
+    assert abs(bench.flops_survey(10, 0) - 2.712e6) < 2e3 and abs(bench.flops_survey(10, 1) - bench.flops_survey(10, 0) - 35.2e3) < 1
+    assert abs(bench.flops_survey(20, 0) - 20.67e6) < 1e4 and abs(bench.flops_survey(20, 1) - bench.flops_survey(20, 0) - 128.0e3) < 1
+    assert bench.hbm_bytes_per_solve(10, False, False) == 1116
+    fl, parts = bench.flops_run(10, 56.0, 6.0)
+    assert fl == parts["setup"] + 6.0 * parts["factor"] + 56.0 * parts["iteration"]
+
+
+def test_pack_params_half_defaults_follow_the_horizon():
+    """`half` defaults to what bmpc_default_params chose: the reference's 5 at h = 10 (REF:101-105), h / 2 otherwise."""
+    import biped_mpc_py_amd as bm
+    for h, want in ((10, 5), (16, 8), (20, 10)):
+        mpc = bm.MPC()
+        mpc.h = h
+        assert bm.pack_params(mpc, bm.Biped()).half == want
+        assert bm.pack_params(mpc, bm.Biped(), half=3).half == 3
+        mpc.half = 4
+        assert bm.pack_params(mpc, bm.Biped()).half == 4

@@ -34,30 +34,4 @@ def phases(t, dt, h):
     return np.array([int(v // dt) % h for v in np.asarray(t, float).reshape(-1)], np.int32)
 
 
-def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_mu=False):
-    """SURVEY 8(d) synthetic generator (same distribution as oracle/gen_golden.synth_state)."""
-    rng = np.random.default_rng(seed)
-    x_fb = np.concatenate([
-        rng.uniform(-0.2, 0.2, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(0.45, 0.60, (B, 1)),
-        rng.uniform(-0.5, 0.5, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(-0.2, 0.2, (B, 1))], 1)
-    foot = np.zeros((B, 6))
-    for j, sgn in enumerate((1.0, -1.0)):
-        foot[:, 3 * j + 0] = x_fb[:, 3] - 0.0195 + rng.uniform(-0.05, 0.05, B)
-        foot[:, 3 * j + 1] = x_fb[:, 4] + sgn * (0.089 + rng.uniform(-0.03, 0.03, B))
-    half = half or (5 if h == 10 else h // 2)
-    x_cmd = np.tile(np.array([0, 0, 0, 0, 0, 0.55, 0, 0, 0, 0, 0, 0.0]), (B, 1))
-    if vx_cmd:
-        x_cmd[:, 9] = rng.uniform(-0.5, 0.5, B)
-    if gait == "standing":
-        phase = np.zeros(B, np.int32)
-        contact = np.ones((B, h, 2), np.uint8)
-    else:
-        leg0 = (np.arange(4 * half) // half) % 2 == 0
-        table = np.stack([leg0, ~leg0], 1).astype(np.uint8)
-        phase = rng.integers(0, h, B).astype(np.int32)
-        contact = np.stack([table[k:k + h] for k in phase])
-        if gait == "mixed":                      # config 4: standing or any walking phase
-            stand = rng.integers(0, h + 1, B) == 0
-            contact[stand] = 1
-    mu = rng.uniform(0.3, 0.9, (B, h, 2)) if per_step_mu else None
-    return dict(x_fb=x_fb, foot=foot, contact=contact, phase=phase, x_cmd=x_cmd, mu=mu, half=half)
+from biped_mpc_py_amd.synth import synth_batch  # noqa: E402,F401  (SURVEY 8(d) generator, shared with bench.py)

@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import biped_mpc_py_amd as bm           # noqa: E402
-from bench import synth                  # noqa: E402
+from biped_mpc_py_amd.synth import synth_batch  # noqa: E402
 
 
 def load_sets(d):
@@ -35,7 +35,8 @@ def main():
         k, v = a.split("=")
         grid[k] = [float(x) if "." in x or "e" in x else int(x) for x in v.split(",")]
     sets = load_sets(d)
-    xb, fb, cb, pb = synth(4096, 10, 1)
+    _s = synth_batch(4096, 10, 1)
+    xb, fb, cb, pb = _s["x_fb"], _s["foot"], _s["contact"], _s["phase"]
     keys = list(grid)
     print("%-40s %9s | " % ("options", "ms/4096") + " | ".join("%-22s" % n for n, _ in sets) + " | bench its/nf")
     for combo in itertools.product(*[grid[k] for k in keys]):

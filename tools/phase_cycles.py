@@ -2,11 +2,12 @@ import sys, numpy as np, torch, ctypes as C
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import biped_mpc_py_amd as bm
 from biped_mpc_py_amd import _lib
-from bench import synth
+from biped_mpc_py_amd.synth import synth_batch
 B=int(sys.argv[1]) if len(sys.argv)>1 else 256
 h=10
 s=bm.BatchSolver(max_batch=B)
-x,f,c,p=synth(B,h,1)
+_s=synth_batch(B,h,1)
+x,f,c,p=_s["x_fb"].astype(np.float32),_s["foot"].astype(np.float32),_s["contact"],_s["phase"]
 dev=torch.device('cuda',0)
 prof=torch.zeros((B,16),dtype=torch.int64,device=dev)
 _lib.check(s._lib.bmpc_debug_set_profile(s._h, prof.data_ptr()))
