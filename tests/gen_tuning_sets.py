@@ -1,6 +1,6 @@
 """Regenerates tests/golden/tuning/big_*.npz: 768 random instances of the BASELINE config shapes (SURVEY 8(d)
 generator, tests/util.synth_batch) solved by the fp64 oracle (oracle/bmpc_oracle.solve_mpc, KKT-certified).
-Inputs are rounded to fp32 first, because that is what crosses the C ABI.  ~6 minutes on 8 cores:
+Inputs are rounded to fp32 first, because that is what crosses the C ABI.  About a minute on 8 cores:
 
     python tests/gen_tuning_sets.py [out_dir]
 
@@ -26,13 +26,20 @@ CFGS = [("big_stand10", 10, "standing", 11, {}, 256),
 
 
 def solve_one(args):
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):          # one BLAS thread per worker process
+        return _solve_one(args)
+
+
+def _solve_one(args):
     h, half, x, f, c, ph, xc, mu = args
     m, b = orc.MPC(), orc.Biped()
     m.h = h
     m.x_cmd = xc
     t = ph * m.dt + 0.5 * m.dt
-    _, ct = orc.solve_mpc(x, t, f, m, b, c, half=half, mu_steps=mu)
-    return ct
+    _, ct, info = orc.solve_mpc(x, t, f, m, b, c, half=half, mu_steps=mu, return_info=True)
+    k = info["kkt"]
+    return ct, np.array([k["stationarity"], k["primal_eq"], k["primal_ineq"], k["dual"], k["complementarity"]]), int(info["polished"])
 
 
 if __name__ == "__main__":
@@ -47,7 +54,10 @@ if __name__ == "__main__":
                  None if mu32 is None else mu32[i]) for i in range(B)]
         t0 = time.time()
         with Pool(min(8, os.cpu_count() or 1)) as p:
-            ref = np.stack(p.map(solve_one, args))
+            res = p.map(solve_one, args)
+        ref = np.stack([o[0] for o in res])
+        kkt = np.stack([o[1] for o in res])
+        polished = np.array([o[2] for o in res], np.int32)
         print(name, "oracle time %.0f s" % (time.time() - t0))
         np.savez(os.path.join(out, name + ".npz"), ref=ref, x_fb=x32, foot=f32, contact=s["contact"], phase=s["phase"],
-                 x_cmd=s["x_cmd"], mu=(np.zeros(0) if mu32 is None else mu32), h=h, half=s["half"])
+                 x_cmd=s["x_cmd"], mu=(np.zeros(0) if mu32 is None else mu32), h=h, half=s["half"], kkt=kkt, polished=polished)
