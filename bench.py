@@ -164,9 +164,15 @@ def _cpu_one(args):
     return z[13 * h:].reshape(h, 12), t1 - t0, t2 - t1
 
 
+def _log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(s, h, dt, n_sample):
-    """Reference-style CPU path on the first n_sample instances: single-core latency (this process, one
-    BLAS thread) and all-core rate (one process per core, pool start-up and imports excluded)."""
+    """Reference-style CPU path on the first n_sample instances: single-core latency (ONE worker process
+    busy, one BLAS thread) and all-core rate (one process per core); pool start-up and imports excluded.
+    Everything runs in spawned workers: this process holds torch and the HIP runtime, and neither the BLAS
+    thread limits nor a fork belong in it.  Every wait is bounded."""
     import multiprocessing as mp
     import numpy as np
     try:
@@ -181,21 +187,24 @@ def cpu_baseline(s, h, dt, n_sample):
                 s["x_cmd"][i] if s.get("use_x_cmd") else None, None if s["mu"] is None else s["mu"][i],
                 h, s["half"], full)
 
-    _cpu_init()
     n1 = min(8, n_sample)
-    _cpu_one(arg(0, False))                                             # warm
-    single = [_cpu_one(arg(i, False)) for i in range(n1)]
-    asm_ms = 1e3 * float(np.mean([o[1] for o in single]))
-    sol_ms = 1e3 * float(np.mean([o[2] for o in single]))
+    wait = 240
     with mp.get_context("spawn").Pool(cores, initializer=_cpu_init) as pool:
-        pool.map(_cpu_one, [arg(i % n_sample, False) for i in range(2 * cores)])      # start-up, imports
+        _log(f"cpu_baseline: {cores} workers starting")
+        pool.map_async(_cpu_one, [arg(i % n_sample, False) for i in range(2 * cores)], chunksize=1).get(wait)   # start-up, imports
+        _log("cpu_baseline: workers warm; single-core latency")
+        single = pool.map_async(_cpu_one, [arg(i, False) for i in range(n1)], chunksize=n1).get(wait)     # one worker, the others idle
+        asm_ms = 1e3 * float(np.mean([o[1] for o in single]))
+        sol_ms = 1e3 * float(np.mean([o[2] for o in single]))
+        _log(f"cpu_baseline: {asm_ms:.1f} + {sol_ms:.1f} ms per solve on one core; all-core rate on {n_sample} instances")
         t0 = time.perf_counter()
-        out = pool.map(_cpu_one, [arg(i, False) for i in range(n_sample)])
+        out = pool.map_async(_cpu_one, [arg(i, False) for i in range(n_sample)]).get(wait)
         wall = time.perf_counter() - t0
         nfull = min(n_sample, 4 * cores)
         t0 = time.perf_counter()
-        outf = pool.map(_cpu_one, [arg(i, True) for i in range(nfull)])
+        outf = pool.map_async(_cpu_one, [arg(i, True) for i in range(nfull)]).get(wait)
         wallf = time.perf_counter() - t0
+    _log("cpu_baseline: done")
     ctrl_full = np.stack([o[0] for o in outf])
     ctrl_plain = np.stack([o[0] for o in out])
     cb = dict(value=n_sample / wall, unit="solves/s", cores=cores, kind="port",
@@ -204,7 +213,7 @@ def cpu_baseline(s, h, dt, n_sample):
                      f"(oracle.build_sparse_qp, REF:203-286) + a plain fp64 Mehrotra interior-point solve without "
                      f"polish (what REF:297 asks cvxopt for; cvxopt itself is absent from the image); one process "
                      f"per core, one BLAS thread each, pool start-up and imports excluded; single-core latency "
-                     f"from {n1} instances in this process",
+                     f"from {n1} instances on one worker with the others idle",
               oracle_with_polish={"value": nfull / wallf, "unit": "solves/s", "instances": nfull,
                                   "note": "oracle.solve_mpc as the parity tests use it (IPM + active-set polish + certificate)"})
     return ctrl_full, ctrl_plain, cb
@@ -269,6 +278,8 @@ def run_rank(args):
                  mu=None if s["mu"] is None else torch.from_numpy(s["mu"][a:b].astype(np.float32)).to(dev))
         return t
 
+    if rank == 0:
+        _log(f"rank 0 of {world}: config {args.config}, h = {h}, {B} instances on this GPU")
     tin = dev_inputs(lo, hi)
     o_u = torch.empty((B, h, 12), dtype=torch.float32, device=dev)
     o_s = torch.empty((B, h, 13), dtype=torch.float32, device=dev)
@@ -326,6 +337,8 @@ def run_rank(args):
         fence()
         elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))     # average launch duration, timed region
+    if rank == 0:
+        _log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms per step, kernel {kernel_ms:.3f} ms")
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -394,6 +407,7 @@ def run_rank(args):
             if not same:
                 raise SystemExit("gathered controls differ from the single-GPU result")
     if rank == 0:
+        _log("host-pointer (PCIe-inclusive) rate")
         # whole-batch wall clock through the host-pointer entry (H2D + kernel + D2H, fp32 over PCIe)
         xs = [s[k][lo:hi] for k in ("x_fb", "foot", "contact", "phase")]
         kw = dict(x_cmd=s["x_cmd"][lo:hi] if use_x_cmd else None, mu=None if s["mu"] is None else s["mu"][lo:hi])
@@ -406,8 +420,15 @@ def run_rank(args):
                                    "what": "bmpc_solve_batch on host arrays: H2D + kernel + D2H + fp64 conversion, one GPU"}
         if world == 1 and args.cpu_sample > 0:
             n = min(args.cpu_sample, B)
-            ref_full, ref_plain, cb = cpu_baseline(s, h, mpc.dt, n)
             got = o_u.cpu().numpy().astype(np.float64)
+            try:
+                ref_full, ref_plain, cb = cpu_baseline(s, h, mpc.dt, n)
+            except Exception as e:          # a stuck or failed worker pool must not cost the GPU measurement
+                _log(f"cpu_baseline failed: {type(e).__name__}: {e}")
+                line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
+                                        "sample": f"unavailable in this run: {type(e).__name__}"}
+                print(json.dumps(line), flush=True)
+                return
 
             def rel(a, b):
                 k = len(b)

@@ -118,7 +118,7 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
              hipStream_t st) {
   constexpr int NT = bmpc::Dims<H>::NT;
-  hipLaunchKernelGGL((bmpc::solve_kernel<H, double>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
+  hipLaunchKernelGGL((bmpc::solve_kernel<H>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
                      phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg);
   HIP_TRY(hipGetLastError());
   return BMPC_OK;

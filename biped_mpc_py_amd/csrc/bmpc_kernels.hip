@@ -13,50 +13,47 @@
 //   solve            the unique minimiser REF:297 asks cvxopt for, by ADMM with active-set adaptive
 //                    penalties; unpack controls / states (REF:300-304)
 //
-// Thread map: lane l < 6H  <->  (step j = l / 6, component c = l % 6).  A lane owns
-//   * wrench row c of step j (tau_xyz, F_xyz): one row of Gt and of V = (Gt + F)^-1 in VGPRs,
-//   * control variable c of both feet at step j (v = [f(3), m(3)] per foot),
-//   * the box row of those two variables and general row c (4 friction + 2 line-foot) of both feet.
+// Thread map: TWO lanes per wrench row.  Lane l  <->  (row = l / 2, half hf = l % 2), row = (step j = row / 6,
+// component c = row % 6).  The two lanes of a row are neighbours, so they exchange through DPP (no LDS, no
+// barrier).  Between them they split
+//   * the row of V = (Gt + F)^-1 and of Gt by COLUMN halves: lane hf holds the columns of steps
+//     [hf H/2, (hf + 1) H/2) -- half the sweep, half the mat-vecs, half the registers each,
+//   * the per-step control-space work by FOOT: lane hf owns control variable c of foot hf at step j
+//     (v = [f(3), m(3)] per foot), its box row and general row c (4 friction + 2 line-foot) of that foot.
+// A workgroup is 2 waves at h = 10 (3 at h = 16, 4 at h = 20), every lane stays under 256 registers, and two
+// waves share a SIMD: one wave's LDS round trips and barriers are covered by the other's arithmetic.
 // Arithmetic: data and the application of the preconditioner K^-1 (V sweep, V mat-vec, stored 6x6
 // factors) are f32, the sweep and mat-vecs on the packed-f32 pipe; the 6x6 block algebra, the
-// iterates and the KKT residual the preconditioner is applied to are RT (f64 by default), which is
-// what pins the fixed point to the fp64 optimum.
+// iterates and the KKT residual the preconditioner is applied to are f64, which is what pins the
+// fixed point to the fp64 optimum.
+//
+// The file also compiles as plain C++ for tests/emu (BMPC_EMU: one std::thread per lane, barriers for
+// __syncthreads and for the cross-lane operations) so that the kernel's logic is testable without a GPU.
 
+#ifndef BMPC_EMU
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace bmpc {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef double RT;                       // iterate / residual / block-algebra arithmetic
 
-// Explicit live-range splitting.  With one wave per SIMD the 256 accumulation registers are free;
-// the values that merely have to survive the register-hungry factorisation are moved there by hand
-// and back afterwards (2 moves per factorisation).  Left to the allocator they get an AGPR home for
-// their whole life and pay a copy at every use in every iteration.
-struct Parked64 { int lo, hi; };
-__device__ __forceinline__ void park(float v, float& slot) {
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot) : "v"(v));
+#ifndef BMPC_EMU
+__device__ __forceinline__ double rcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ __forceinline__ float rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq_approx(float x) { return __builtin_amdgcn_rsqf(x); }
+// value of the other lane of the pair (lane ^ 1): DPP quad_perm [1, 0, 3, 2].  Call with all lanes active.
+__device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+#define BMPC_FENCE() asm volatile("" ::: "memory")
+#endif
+__device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
+__device__ __forceinline__ double pair_swap(double v) {
+  const int lo = pair_swap_i(__double2loint(v)), hi = pair_swap_i(__double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void unpark(float& v, const float& slot) {
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot));
-}
-__device__ __forceinline__ void park(double v, Parked64& slot) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot.lo) : "v"(lo));
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot.hi) : "v"(hi));
-}
-__device__ __forceinline__ void unpark(double& v, const Parked64& slot) {
-  int lo, hi;
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(slot.lo));
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(slot.hi));
-  v = __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void park(float v, Parked64& slot) {     // RT = float builds
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot.lo) : "v"(v));
-}
-__device__ __forceinline__ void unpark(float& v, const Parked64& slot) {
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot.lo));
-}
+__device__ __forceinline__ f2 pair_swap(f2 v) { return f2{pair_swap(v.x), pair_swap(v.y)}; }
 
 struct DevParams {
   int h, half, max_iter, check_every, adapt_start, adapt_every, max_refactor, pad0;
@@ -77,49 +74,63 @@ struct DebugOut {            // all nullable, fp64, device pointers
 
 template <int H>
 struct Dims {
-  static constexpr int NW = 6 * H;                       // wrench rows = threads that work
-  static constexpr int NT = ((NW + 63) / 64) * 64;       // threads per workgroup (whole waves)
+  static_assert(H % 2 == 0, "the column halves are whole steps");
+  static constexpr int NW = 6 * H;                       // wrench rows
+  static constexpr int HN = NW / 2;                      // columns of V a lane holds (= 3 H)
+  static constexpr int HH = H / 2;                       // steps per column half
+  static constexpr int NT = ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
+  static constexpr int NWV = NT / 64;
   static constexpr int NPAIR = H * (H - 1) / 2;          // (i > j) step pairs
+  // A vector over the wrench rows that both column halves read is stored in LDS as two 16-byte aligned
+  // halves: entry i sits at slot(i).  The halves start 4 k dwords apart with 4 k mod 64 outside (-4, 4), so
+  // the two addresses of a wave's ds_read_b128 (even lanes: half 0, odd lanes: half 1) never share a bank.
+  static constexpr int HNP = ((HN + 3) / 4) * 4;
+  static constexpr int VL = 2 * HNP;
+  static_assert(HNP % 64 >= 4 && HNP % 64 <= 60, "halves of a two-half vector would collide on LDS banks");
+  // Gt row half: 3 component groups x HH steps, padded to whole float4s
+  static constexpr int GH = ((3 * HH + 3) / 4) * 4;
+  static constexpr int GS = (GH % 16 == 0 && GH % 64 != 16 && GH % 64 != 48) ? GH + 4 : GH;   // stride of the 4 gamma copies
 };
+template <int H>
+__device__ __forceinline__ constexpr int slot(int i) { return i < Dims<H>::HN ? i : i - Dims<H>::HN + Dims<H>::HNP; }
 
 // LDS image of one instance.  The factor scratch (f64 6x6 blocks) and the per-iteration exchange
-// vectors (+ the set-up-only step data) are never live at the same time and share one region, which
-// brings h = 10 under 20 KB: eight workgroups per CU.
-template <int H, typename RT>
+// vectors (+ the set-up-only step data) are never live at the same time and share one region.
+template <int H>
 struct alignas(16) FacScratch {
   double M0[H][6][6];        // D0 -> Ka^-1 D0 W_0^-1
   double M1[H][6][6];        // D1 -> Ka^-1
   double M2[H][6][6];        // B = T' D1 T -> L_0
-  double ex[H][1][6];        // pivot-column exchange for the cooperative 6x6 sweep
+  double ex[H][6];           // pivot-column exchange for the cooperative 6x6 sweep
 };
-template <int H, typename RT>
+template <int H>
 struct IterScratch {
   static constexpr int NW = Dims<H>::NW;
   RT wg[H][2][6];            // y + rho (A x - z) on the general rows
-  alignas(16) RT bwT[6][H];  // net wrench of x, component-major: a lane reads its 3 H inputs of Gt contiguously
+  alignas(16) RT bwT[6][H];  // net wrench of x, component-major: a lane reads its inputs of Gt contiguously
   RT gb[NW];                 // wrench-space gradient Gt b + qt
   alignas(16) float r32[H][2][6];   // KKT residual, control space
-  alignas(16) float beta[NW];
+  alignas(16) float beta[Dims<H>::VL];   // d .* L' r, two-half layout
   alignas(16) float gam[NW];
-  // gamma again, component-major in two groups (torque, force) for the gradient increment; the second group
-  // starts 4 banks after a multiple of 32 so that the two addresses of a read never share a bank
-  alignas(16) float gamT[2][((3 * H + 35) / 32) * 32 + 4 > 3 * H ? ((3 * H + 31) / 32) * 32 + 4 : 3 * H];
+  // gamma again for the gradient increment: per (component group = torque / force, column half) the 3 HH
+  // values a lane multiplies with its Gt row half, contiguous, zero padded to GH
+  alignas(16) float gamT[4][Dims<H>::GS];
   // set-up only
   RT Rv[H][9];               // R_inv (REF:160-164)
   RT Pre[H][9];              // prefix sums of R_inv
   RT err[H][12];             // free response - reference
 };
-template <int H, typename RT>
+template <int H>
 struct alignas(16) Smem {
   static constexpr int NW = Dims<H>::NW;
   union alignas(16) {
-    FacScratch<H, RT> fac;
-    IterScratch<H, RT> itv;
+    FacScratch<H> fac;
+    IterScratch<H> itv;
   } u;
-  RT xs[H][2][6];            // x (relaxed iterate); re-read per iteration instead of living in VGPRs
-  alignas(16) float piv[2][Dims<H>::NT];   // sweep pivot column, double buffered (slots >= NW: idle lanes)
-  // block-diagonal part of K^-1.  Foot-major: a lane's row then sits at 24 B x lane + const, which the 32
-  // LDS banks serve without conflicts (step-major interleaves the feet and collides every third step)
+  RT xs[H][2][6];            // x (relaxed iterate) for the exact rebuilds and the state roll-out
+  alignas(16) float piv[2][Dims<H>::VL];   // sweep pivot column, double buffered, two-half layout
+  alignas(16) float dsc[Dims<H>::VL];      // Jacobi scaling of the current factorisation
+  // block-diagonal part of K^-1.  Foot-major: a lane's row sits at 48 B x row + const.
   // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
   // products against (t, gamma) and run as one packed FMA per term.
   alignas(16) float LG[2][H][6][6][2];  // {L, G L}:   L_j = D^-1 W' F            [foot][step][var][wrench comp]
@@ -135,26 +146,15 @@ struct alignas(16) Smem {
   RT Gu[6][6];               // mu-free part of the general rows of a foot block, and its transpose
   RT GuT[6][6];
   float eyz[6];              // body y and z axes in the world frame (columns 1, 2 of eul2rotm(x_fb))
-  float red[4][Dims<H>::NT / 64];
+  float red[4][Dims<H>::NWV];
 };
 
 __device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
 
-// Workgroup synchronisation point.  A one-wave workgroup needs no hardware barrier and no wait: the
-// LDS executes a wave's instructions in issue order, so a ds_write is complete for all 64 lanes
-// before the wave's next ds_read starts.  What remains is a compiler-level fence that keeps LDS
-// accesses on their side of the point (the s_waitcnt lgkmcnt(0) that __syncthreads() would add costs
-// a full LDS round trip per exchange, ~10 % of the kernel).  Larger workgroups take the real barrier.
-template <int NT>
-__device__ __forceinline__ void wg_sync() {
-  if constexpr (NT == 64) asm volatile("" ::: "memory");
-  else __syncthreads();
-}
-
-// max over the workgroup of 4 NON-NEGATIVE floats (or NaN) at once.  The order of such floats is
-// the order of their bit patterns, with NaN above everything, so the reduction is an unsigned max:
-// six DPP steps per value inside a wave (shifts read 0 = the neutral element where a source lane does
-// not exist), then the waves of a larger workgroup combine through LDS.  NaNs propagate.
+#ifndef BMPC_EMU
+// max over a wave of a NON-NEGATIVE float (or NaN).  The order of such floats is the order of their bit
+// patterns, with NaN above everything, so the reduction is an unsigned max: six DPP steps (shifts read
+// 0 = the neutral element where a source lane does not exist).  NaNs propagate.
 __device__ __forceinline__ unsigned wave_umax(unsigned v) {
 #define BMPC_DPP_MAX(ctrl) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, true); v = v > o ? v : o; }
   BMPC_DPP_MAX(0x111)   // row_shr:1
@@ -166,26 +166,26 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
 #undef BMPC_DPP_MAX
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+#endif
+// max over the workgroup of 4 such values at once; the waves combine through LDS.  All threads call.
 template <int NT>
 __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(wave_umax(__float_as_uint(v[q])));
-  if constexpr (NT > 64) {
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) red[q][w] = v[q];
-    }
-    wg_sync<NT>();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned m = __float_as_uint(red[q][0]);
-#pragma unroll
-      for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
-      v[q] = __uint_as_float(m);
-    }
-    wg_sync<NT>();
+    for (int q = 0; q < 4; ++q) red[q][w] = v[q];
   }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned m = __float_as_uint(red[q][0]);
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
+    v[q] = __uint_as_float(m);
+  }
+  __syncthreads();
 }
 
 // out[b] += sum_q w[q] * M[q][b] for a 6x6 f64 matrix in LDS: whole rows are fetched (three 16-byte
@@ -204,53 +204,37 @@ __device__ __forceinline__ void row_times_mat6(const double (&w)[6], const doubl
   }
 }
 
-// Cooperative symmetric sweep of NM 6x6 SPD matrices per step: lane (j, c) holds row c of each.
-// On exit the rows hold the INVERSES.  All threads of the workgroup must call (barriers inside).
-template <int H, typename RT, int NM>
-__device__ __forceinline__ void sweep6(double (&m)[NM][6], Smem<H, RT>& sm, bool valid, int j, int c) {
-  constexpr int NT = Dims<H>::NT;
+// Cooperative symmetric sweep of one 6x6 SPD matrix per step: the lanes with `on` (one per row (j, c)) hold
+// row c.  On exit the rows hold the INVERSE.  All threads of the workgroup must call (barriers inside).
+template <int H>
+__device__ __forceinline__ void sweep6(double (&m)[6], Smem<H>& sm, bool on, int j, int c) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    if (valid) {
+    if (on) sm.u.fac.ex[j][c] = m[k];
+    __syncthreads();
+    if (on) {
+      double col[6];
 #pragma unroll
-      for (int q = 0; q < NM; ++q) sm.u.fac.ex[j][q][c] = m[q][k];
-    }
-    wg_sync<NT>();
-    if (valid) {
+      for (int b = 0; b < 6; ++b) col[b] = sm.u.fac.ex[j][b];
+      // reciprocal by v_rcp_f64 + two Newton steps (a correctly rounded IEEE division is ~40 dependent instructions)
+      double pinv = rcp_approx(col[k]);
+      pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
+      pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
+      const bool isp = (c == k);
+      const double t = isp ? -pinv : m[k] * pinv;
 #pragma unroll
-      for (int q = 0; q < NM; ++q) {
-        double col[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) col[b] = sm.u.fac.ex[j][q][b];
-        // reciprocal by v_rcp_f64 + two Newton steps (a correctly rounded IEEE division is ~40 dependent instructions)
-        double pinv = __builtin_amdgcn_rcp(col[k]);
-        pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
-        pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
-        const bool isp = (c == k);
-        const double t = isp ? -pinv : m[q][k] * pinv;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          if (b == k) continue;
-          m[q][b] = isp ? col[b] * pinv : fma(-t, col[b], m[q][b]);
-        }
-        m[q][k] = t;            // pivot lane: -1/p ; others: a_ik / p
+      for (int b = 0; b < 6; ++b) {
+        if (b == k) continue;
+        m[b] = isp ? col[b] * pinv : fma(-t, col[b], m[b]);
       }
+      m[k] = t;            // pivot lane: -1/p ; others: a_ik / p
     }
-    wg_sync<NT>();
+    __syncthreads();
   }
   // swept matrix = -A^-1
 #pragma unroll
-  for (int q = 0; q < NM; ++q)
-#pragma unroll
-    for (int b = 0; b < 6; ++b) m[q][b] = -m[q][b];
+  for (int b = 0; b < 6; ++b) m[b] = -m[b];
 }
-
-__device__ __forceinline__ void sincos_rt(double x, double* s, double* c) { sincos(x, s, c); }
-__device__ __forceinline__ void sincos_rt(float x, float* s, float* c) { sincosf(x, s, c); }
-__device__ __forceinline__ double min_rt(double a, double b) { return fmin(a, b); }
-__device__ __forceinline__ float min_rt(float a, float b) { return fminf(a, b); }
-__device__ __forceinline__ double max_rt(double a, double b) { return fmax(a, b); }
-__device__ __forceinline__ float max_rt(float a, float b) { return fmaxf(a, b); }
 
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* o) {
@@ -278,8 +262,8 @@ __device__ __forceinline__ void general_rows(float mu, const float* ey, const fl
   }
 }
 
-template <int H, typename RT>
-__global__ void __launch_bounds__(Dims<H>::NT)
+template <int H>
+__global__ void __launch_bounds__(Dims<H>::NT, 2)
 solve_kernel(const DevParams P, const int B,
              const float* __restrict__ x_fb, const float* __restrict__ foot,
              const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase,
@@ -289,8 +273,12 @@ solve_kernel(const DevParams P, const int B,
              int32_t* __restrict__ status_out, int32_t* __restrict__ nfactor_out,
              const DebugOut dbg) {
   constexpr int NW = Dims<H>::NW;
+  constexpr int HN = Dims<H>::HN;
+  constexpr int HH = Dims<H>::HH;
+  constexpr int HNP = Dims<H>::HNP;
+  constexpr int GH = Dims<H>::GH;
   constexpr int NT = Dims<H>::NT;
-  __shared__ Smem<H, RT> sm;
+  __shared__ Smem<H> sm;
 
   const int inst = blockIdx.x;
   if (inst >= B) return;
@@ -299,14 +287,16 @@ solve_kernel(const DevParams P, const int B,
 #define BMPC_STAMP(k) if (dbg.prof) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
   if (dbg.prof) t_start = clock64();
   const int l = threadIdx.x;
-  const bool valid = l < NW;
-  const int j = valid ? l / 6 : 0;
-  const int c = valid ? l % 6 : 0;
+  const int hf = l & 1;                        // column half of V / Gt, and the foot this lane owns
+  const int f = hf;
+  const int row = l >> 1;
+  const bool valid = row < NW;
+  const int j = valid ? row / 6 : 0;
+  const int c = valid ? row % 6 : 0;
+  const int jb = hf * HH;                      // first step of this lane's column half
   const RT dt = (RT)P.dt;
   // 0/1 masks of this lane's component: runtime picks are done arithmetically (select chains over
   // register arrays get demoted to scratch by the compiler)
-  // (the factor-only masks are rebuilt inside factor() so that they do not occupy registers during
-  // the iterations)
   RT mk3[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) mk3[k] = (c % 3 == k) ? (RT)1 : (RT)0;
@@ -341,7 +331,8 @@ solve_kernel(const DevParams P, const int B,
       fr[0] = fx; fr[1] = fy; fr[2] = 0; fr[3] = fx; fr[4] = fy; fr[5] = 0;
     }
   }
-  if (valid && c == 0) {                       // debug views of the references (tests)
+  const bool lead = valid && c == 0 && hf == 0;   // one lane per step
+  if (lead) {                                  // debug views of the references (tests)
     if (dbg.x_ref) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) dbg.x_ref[((size_t)inst * H + j) * 12 + i] = (double)xr[i];
@@ -355,9 +346,9 @@ solve_kernel(const DevParams P, const int B,
   RT Pj[9];                                    // prefix sum of R_inv up to this lane's step
   {
     RT sy, cy, sp, cp, sr, cr;                 // REF:151-153: yaw = x[0], pitch = x[1], roll = x[2]
-    sincos_rt(xr[0], &sy, &cy);
-    sincos_rt(xr[1], &sp, &cp);
-    sincos_rt(xr[2], &sr, &cr);
+    sincos(xr[0], &sy, &cy);
+    sincos(xr[1], &sp, &cp);
+    sincos(xr[2], &sr, &cr);
     // Rot = Rx(roll) Ry(pitch) Rz(yaw)   (scipy 'zyx' extrinsic, REF:154-156)
     const RT Rot[9] = {cp * cy, -cp * sy, sp,
                        cr * sy + sr * sp * cy, cr * cy - sr * sp * sy, -sr * cp,
@@ -375,16 +366,16 @@ solve_kernel(const DevParams P, const int B,
         Iw[3 * a + b] = Rot[a] * T[b] + Rot[3 + a] * T[3 + b] + Rot[6 + a] * T[6 + b];   // Rot' Iinv Rot = (Rot' I Rot)^-1
     const RT tp = sp / cp;
     const RT Rv[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};             // REF:160-164 inverted
-    if (valid && c == 0) {
+    if (lead) {
 #pragma unroll
       for (int q = 0; q < 9; ++q) { sm.Iw[j][q] = Iw[q]; sm.u.itv.Rv[j][q] = Rv[q]; }
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) sm.rr[j][f][a] = fr[3 * f + a] - xr[3 + a];           // REF:174-175
+        for (int a = 0; a < 3; ++a) sm.rr[j][ft][a] = fr[3 * ft + a] - xr[3 + a];         // REF:174-175
     }
   }
-  wg_sync<NT>();
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < 9; ++q) Pj[q] = 0;
 #pragma unroll 1
@@ -392,7 +383,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
     for (int q = 0; q < 9; ++q) Pj[q] += sm.u.itv.Rv[s][q];
   if (valid) {
-    if (c == 0) {
+    if (lead) {
 #pragma unroll
       for (int q = 0; q < 9; ++q) sm.u.itv.Pre[j][q] = Pj[q];
     }
@@ -408,12 +399,12 @@ solve_kernel(const DevParams P, const int B,
     }
     e12[5] -= (RT)P.g * dt * dt * (RT)j * j1 / 2;
     e12[11] -= (RT)P.g * dt * j1;
-    if (c == 0) {
+    if (lead) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) { sm.u.itv.err[j][i] = e12[i] - xr[i]; sm.s0[j][i] = e12[i]; }
     }
   }
-  wg_sync<NT>();
+  __syncthreads();
   // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2: one (i, j2) pair per lane and pass
   for (int idx = l; idx < Dims<H>::NPAIR; idx += NT) {
     int i = (int)((1.f + sqrtf(1.f + 8.f * (float)idx)) * 0.5f);     // invert idx = i (i - 1) / 2 + j2
@@ -430,27 +421,26 @@ solve_kernel(const DevParams P, const int B,
         sm.Me[idx][3 * a + b] = (float)(dt * dt * s);
       }
   }
-  wg_sync<NT>();
+  __syncthreads();
 
-  // ------------------------------------------------------------------ B. wrench-space Hessian row
-  // Row of Gt against one component group of the wrench (torque lanes: tau, force lanes: F), laid out
-  // [b][j2] like bwT so that P1 is the same straight-line code for every lane:
-  // torque lane (j,a): Gt[(j,a)][(j2,b)] at b H + j2 ; force lane (j,3+a): Gt[(j,3+a)][(j2,3+a)] at a H + j2, zeros elsewhere
-  float Grow[3 * H];
+  // ------------------------------------------------------------------ B. wrench-space Hessian row (column half)
+  // Half a row of Gt against one component group of the wrench (torque lanes: tau, force lanes: F) over the
+  // steps j2 = jb + jj of this lane's column half, laid out [b][jj]:
+  // torque lane (j,a): Gt[(j,a)][(j2,b)] at b HH + jj ; force lane (j,3+a): Gt[(j,3+a)][(j2,3+a)] at a HH + jj, zeros elsewhere
+  float Grow[GH];
   RT qt = 0;
+  float gdiag = 0.f;                           // Gt[row][row] (for the Jacobi scaling of Gt + F); both lanes of the pair
 #pragma unroll
-  for (int q = 0; q < 3 * H; ++q) Grow[q] = 0.f;
+  for (int q = 0; q < GH; ++q) Grow[q] = 0.f;
   if (valid) {
-    // The step loops run over wave-uniform ranges with per-lane predicates, so the partner blocks
-    // Me[i][j2] are broadcast reads and the (i, j2) work of one i is a batch of independent FMAs.
     if (c < 3) {
       const int a = c;
       RT nw[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) nw[q] = dt * sm.Iw[j][3 * q + a] * (RT)P.Q[6 + q];   // Q_w weighted column
-      RT acc[3 * H];                            // sum_{i > max(j, j2)} (Me_i,j Q Me_i,j2)[a][b] at b H + j2 (then the row itself)
+      RT acc[3 * HH];                           // sum_{i > max(j, j2)} (Me_i,j Q Me_i,j2)[a][b] at b HH + jj
 #pragma unroll
-      for (int q = 0; q < 3 * H; ++q) acc[q] = 0;
+      for (int q = 0; q < 3 * HH; ++q) acc[q] = 0;
       RT s = 0;
 #pragma unroll
       for (int q = 0; q < 3; ++q) s += nw[q] * sm.u.itv.err[j][6 + q];             // i = j term of qt
@@ -464,54 +454,48 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int q = 0; q < 3; ++q) s += u[q] * sm.u.itv.err[i][q] + (act ? nw[q] : (RT)0) * sm.u.itv.err[i][6 + q];
 #pragma unroll
-        for (int j2 = 0; j2 < H - 1; ++j2) {
-          if (j2 < i) {                         // uniform
+        for (int jj = 0; jj < HH; ++jj) {
+          const int j2 = jb + jj;
+          if (j2 < i) {
             const float* m2 = sm.Me[pair_index(i, j2)];
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-              for (int b = 0; b < 3; ++b) acc[b * H + j2] += u[q] * (RT)m2[3 * q + b];
+              for (int b = 0; b < 3; ++b) acc[b * HH + jj] += u[q] * (RT)m2[3 * q + b];
           }
         }
       }
       qt = 2 * s;
 #pragma unroll
-      for (int j2 = 0; j2 < H; ++j2) {
+      for (int jj = 0; jj < HH; ++jj) {
+        const int j2 = jb + jj;
         const RT cnt = (RT)(H - (j > j2 ? j : j2));
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           RT sw = 0;
 #pragma unroll
           for (int q = 0; q < 3; ++q) sw += nw[q] * dt * sm.Iw[j2][3 * q + b];
-          const RT gval = 2 * (acc[b * H + j2] + cnt * sw);
-          Grow[b * H + j2] = (float)gval;
-          acc[b * H + j2] = gval;
+          const RT gval = 2 * (acc[b * HH + jj] + cnt * sw);
+          Grow[b * HH + jj] = (float)gval;
+          if (j2 == j && b == a) gdiag = (float)gval;
+          if (dbg.Gt) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = gval;     // fp64 view of the row (tests)
         }
-      }
-      if (dbg.Gt) {                             // fp64 view of the row (tests)
-#pragma unroll
-        for (int j2 = 0; j2 < H; ++j2)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + b] = (double)acc[b * H + j2];
       }
     } else {
       const int a = c - 3;
       const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
-      RT gdbg[H];
 #pragma unroll
-      for (int j2 = 0; j2 < H; ++j2) {
+      for (int jj = 0; jj < HH; ++jj) {
+        const int j2 = jb + jj;
         // sum_{i = mx}^{H-1} (i - j)(i - j2), closed form: with n terms and offsets d1, d2 (one of them 0)
         const int mx = j > j2 ? j : j2;
         const int n = H - mx, d1 = mx - j, d2 = mx - j2;
         const int s2 = n * d1 * d2 + (d1 + d2) * (n * (n - 1) / 2) + (n - 1) * n * (2 * n - 1) / 6;
         const RT gval = 2 * ((RT)P.Q[3 + a] * kp * kp * (RT)s2 + (RT)P.Q[9 + a] * kvv * kvv * (RT)n);
 #pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2) Grow[a2 * H + j2] = (a2 == a) ? (float)gval : 0.f;
-        gdbg[j2] = gval;
-      }
-      if (dbg.Gt) {
-#pragma unroll
-        for (int j2 = 0; j2 < H; ++j2) dbg.Gt[((size_t)inst * NW + l) * NW + 6 * j2 + 3 + a] = (double)gdbg[j2];
+        for (int a2 = 0; a2 < 3; ++a2) Grow[a2 * HH + jj] = (a2 == a) ? (float)gval : 0.f;
+        if (j2 == j) gdiag = (float)gval;
+        if (dbg.Gt) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + 3 + a] = gval;
       }
       RT s = 0;
 #pragma unroll
@@ -521,27 +505,27 @@ solve_kernel(const DevParams P, const int B,
       }
       qt = 2 * s;
     }
-    if (dbg.qt) dbg.qt[(size_t)inst * NW + l] = (double)qt;
+    if (dbg.qt && hf == 0) dbg.qt[(size_t)inst * NW + row] = (double)qt;
   }
+  gdiag += pair_swap(gdiag);                   // one lane of the pair holds it, the other 0
   if (dbg.assemble_only) return;
   if (dbg.prof) t_setup = clock64() - t_start;
 
-  // ------------------------------------------------------------------ C. constraint data
+  // ------------------------------------------------------------------ C. constraint data (own foot)
   // General rows of a foot block: G = Gu - mu * [rows 0..3, column 2].  Gu (the mu-free part) is the same
   // for every step and foot of the instance and lives in LDS (plus its transpose); a lane keeps only
-  // the two mu terms it needs.  Coefficients used with the f64 iterates are kept as RT so that no
-  // f32 copy + hoisted conversion doubles their register footprint.
-  RT lb[2], ub[2], R2v[2];
-  bool eqb[2];
-  RT cmu[2];                                  // -mu_f if this lane's variable is f_z (column 2 of the friction rows)
+  // the mu term it needs.
+  RT lb, ub, R2v;
+  bool eqb;
+  RT cmu;                                     // -mu_f if this lane's variable is f_z (column 2 of the friction rows)
   float drf[3];                               // r_0 - r_1 of this step
   {
     float ey[3], ez[3];                       // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
     {
       RT sr, cr, sp, cp, sy, cy;
-      sincos_rt(xfb[0], &sr, &cr);
-      sincos_rt(xfb[1], &sp, &cp);
-      sincos_rt(xfb[2], &sy, &cy);
+      sincos(xfb[0], &sr, &cr);
+      sincos(xfb[1], &sp, &cp);
+      sincos(xfb[2], &sy, &cy);
       ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
       ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
     }
@@ -555,76 +539,56 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int b2 = 0; b2 < 6; ++b2) { sm.Gu[r][b2] = (RT)G[r][b2]; sm.GuT[b2][r] = (RT)G[r][b2]; }
     }
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    {
       const float cont = (float)contact[((size_t)inst * H + j) * 2 + f];
       const float muf = mu_in ? mu_in[((size_t)inst * H + j) * 2 + f] : (float)P.mu;
       if (valid && c == 0) sm.muf[j][f] = muf;
       const int a = c < 3 ? c : c - 3;
       const float ubf = cont * (float)(c < 3 ? P.f_max[a] : P.tau_max[a]);      // REF:240-249
       const float lbf = cont * (float)(c < 3 ? P.f_min[a] : P.tau_min[a]);
-      ub[f] = (RT)ubf;
-      lb[f] = (RT)lbf;
-      eqb[f] = lbf == ubf;
-      R2v[f] = (RT)(float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
-      cmu[f] = c == 2 ? (RT)(-muf) : (RT)0;
+      ub = (RT)ubf;
+      lb = (RT)lbf;
+      eqb = lbf == ubf;
+      R2v = (RT)(float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
+      cmu = c == 2 ? (RT)(-muf) : (RT)0;
     }
 #pragma unroll
     for (int a2 = 0; a2 < 3; ++a2) drf[a2] = (float)sm.rr[j][0][a2] - (float)sm.rr[j][1][a2];
     if (valid) {
       const int a3 = c < 3 ? c : c - 3;
       const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        sm.rx[j][f][c][0] = c < 3 ? sm.rr[j][f][i2] : (RT)0;
-        sm.rx[j][f][c][1] = c < 3 ? sm.rr[j][f][i1] : (RT)0;
-      }
+      sm.rx[j][f][c][0] = c < 3 ? sm.rr[j][f][i2] : (RT)0;
+      sm.rx[j][f][c][1] = c < 3 ? sm.rr[j][f][i1] : (RT)0;
     }
   }
 
   // ------------------------------------------------------------------ D. factor: L, Kn (and their G images), V for penalties rv
-  RT rvb[2], rvg[2];                          // penalties of this lane's box rows / general rows (f32 values)
-#pragma unroll
-  for (int f = 0; f < 2; ++f) { rvb[f] = (RT)(eqb[f] ? P.rho_eq : P.rho); rvg[f] = (RT)P.rho; }
-  RT irvb[2], irvg[2];                        // reciprocals (refreshed with the penalties)
-#pragma unroll
-  for (int f = 0; f < 2; ++f) { irvb[f] = (RT)1 / rvb[f]; irvg[f] = (RT)1 / rvg[f]; }
-  // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
-  // redone there instead of being hoisted into a second, f64, register copy that lives across the loop
-#define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
-  // row l of -(Gt + F)^-1 after the sweep, as float pairs: the sweep and the V mat-vec run on the
-  // packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two lanes of f32 per instruction)
-  f2 Vr[NW / 2];
+  RT rvb, rvg;                                // penalties of this lane's box row / general row (f32 values)
+  rvb = (RT)(eqb ? P.rho_eq : P.rho); rvg = (RT)P.rho;
+  RT irvb = (RT)1 / rvb, irvg = (RT)1 / rvg;  // reciprocals (refreshed with the penalties)
+  // Half a row of -(S (Gt + F) S)^-1 after the sweep (S = Jacobi scaling to unit diagonal), as float pairs:
+  // the sweep and the V mat-vec run on the packed-f32 pipe (v_pk_fma_f32: two f32 per lane and instruction)
+  f2 Vr[HN / 2];
+  float dsc = 1.f;                            // S[row]
 #define VROW(q) Vr[(q) >> 1][(q) & 1]
 
-  float gpark[3 * H];                         // Grow while the block algebra runs
   auto factor = [&]() {
     if (dbg.prof) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
-    // D_f = 2R + A' diag(rv) A, row c of both feet
-    if (valid) {
-      sm.rvg[j][0][c] = (float)rvg[0];
-      sm.rvg[j][1][c] = (float)rvg[1];
-    }
-    wg_sync<NT>();
-    // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so
-    // that none of it is live (= holds registers) during the iterations
-    int co = c;
-    asm volatile("" : "+v"(co));
+    if (valid) sm.rvg[j][f][c] = (float)rvg;
+    __syncthreads();
     double mkd[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) mkd[k] = (co == k) ? 1.0 : 0.0;
+    for (int k = 0; k < 6; ++k) mkd[k] = (c == k) ? 1.0 : 0.0;
     const float lh = (float)P.lh, lt = (float)P.lt;
-    float ey[3], ez[3], muf[2], rf[2][3];
+    float ey[3], ez[3], rf[2][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) { ey[a] = sm.eyz[a]; ez[a] = sm.eyz[3 + a]; }
+    const float muf = sm.muf[j][f];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      muf[f] = sm.muf[j][f];
+    for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) rf[f][a] = (float)sm.rr[j][f][a];
-    }
-    double m3[2][6];                           // rows of D0, D1
+      for (int a = 0; a < 3; ++a) rf[ft][a] = (float)sm.rr[j][ft][a];
     double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
     {
       const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
@@ -644,47 +608,49 @@ solve_kernel(const DevParams P, const int B,
       for (int cc = 0; cc < 6; ++cc) { a1 = fma(mkd[cc], Tm[p][cc], a1); a2 = fma(mkd[cc], Tm[cc][p], a2); }
       Tcol[p] = a1; Trow[p] = a2;
     }
+    // D_f = 2R + A' diag(rv) A: row c of the own foot's block
+    double m3[6];
     if (valid) {
+      float G[6][6];
+      general_rows(muf, ey, ez, lh, lt, G);
+      double wc[6];                            // rho_r * G[r][c]
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        float G[6][6];
-        general_rows(muf[f], ey, ez, lh, lt, G);
-        double wc[6];                          // rho_r * G[r][c]
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          // column c of G_f from the mu-free table; the friction rows' f_z entry is -mu_f
-          const double gc = (double)sm.GuT[c][r] - ((co == 2 && r < 4) ? (double)muf[f] : 0.0);
-          wc[r] = (double)sm.rvg[j][f][r] * gc;
-        }
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          double s = 0.0;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) s = fma(wc[r], (double)G[r][b], s);
-          m3[f][b] = fma(mkd[b], (double)R2v[f] + (double)rvb[f], s);
-        }
-#pragma unroll
-        for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[f][b];
+      for (int r = 0; r < 6; ++r) {
+        // column c of G_f from the mu-free table; the friction rows' f_z entry is -mu_f
+        const double gc = (double)sm.GuT[c][r] - ((c == 2 && r < 4) ? (double)muf : 0.0);
+        wc[r] = (double)sm.rvg[j][f][r] * gc;
       }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s = fma(wc[r], (double)G[r][b], s);
+        m3[b] = fma(mkd[b], (double)R2v + (double)rvb, s);
+      }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[b];
     }
-    wg_sync<NT>();
+    __syncthreads();
     // One 6x6 inverse per step instead of four.  With Y = [W_0^-1; 0] (so W Y = I) and P the D-orthogonal
     // projector I - N Ka^-1 N' D:   L = D^-1 W' F = P Y,   F = (W D^-1 W')^-1 = Y' D L.  In blocks, with
     // B = T' D1 T (Ka = D0 + B) and I - Ka^-1 D0 = Ka^-1 B (no cancellation):
     //   L_0 = Ka^-1 B W_0^-1,   L_1 = T Ka^-1 D0 W_0^-1,   F = (W_0^-T D0) L_0,
-    // W_0^-1 = [[0, I], [I, -[r_0]x]].
-    double brow[6], urow[6];                    // rows c of B and of U = W_0^-T D0
-    double ka[1][6];                            // row c of Ka -> Ka^-1
-    if (valid) {
+    // W_0^-1 = [[0, I], [I, -[r_0]x]].   The two lanes of a row share the work: lane 0 the Ka chain
+    // (B, Ka^-1, L_0, F), lane 1 the D0 chain (Ka^-1 D0 W_0^-1, L_1, T Ka^-1).
+    const bool on0 = valid && hf == 0, on1 = valid && hf == 1;
+    double urow[6];                             // row c of U = W_0^-T D0
+    double ka[6];                               // row c of Ka -> Ka^-1
+    if (on0) {
       double yq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       row_times_mat6(Tcol, sm.u.fac.M1[j], yq);
+      double brow[6];                           // row c of B
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 6; ++q) s = fma(yq[q], Tm[q][b], s);
         brow[b] = s;
-        ka[0][b] = m3[0][b] + s;
+        ka[b] = m3[b] + s;
       }
       // U = W_0^-T D0 = [[0, I], [I, [r_0]x]] D0: rows 0..2 are rows 3..5 of D0, row 3+a is row a + ([r_0]x D0[3:6])_a
       double wti[6];                            // row c of W_0^-T
@@ -714,165 +680,168 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
-    sweep6<H, RT, 1>(ka, sm, valid, j, c);      // -> Ka^-1 (barriers inside: the M1 reads above are done)
-    if (valid) {
+    sweep6<H>(ka, sm, on0, j, c);               // -> Ka^-1 (barriers inside: the M1 reads above are done)
+    if (on0) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.u.fac.M1[j][c][b] = ka[0][b];
+      for (int b = 0; b < 6; ++b) sm.u.fac.M1[j][c][b] = ka[b];
     }
-    double x1[6], x0[6];                        // rows c of Ka^-1 B and Ka^-1 D0
-    if (valid) {
+    __syncthreads();                          // Ka^-1 published
+    double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
+    if (on1) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { x1[b] = 0.0; x0[b] = 0.0; }
-      row_times_mat6(ka[0], sm.u.fac.M2[j], x1);
-      row_times_mat6(ka[0], sm.u.fac.M0[j], x0);
+      for (int b = 0; b < 6; b += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&sm.u.fac.M1[j][c][b]);
+        ka[b] = v.x; ka[b + 1] = v.y;
+      }
     }
-    wg_sync<NT>();                            // B, D0 consumed; Ka^-1 published
-    double fv64[6];                             // row c of F
+    if (on0) row_times_mat6(ka, sm.u.fac.M2[j], xk);
+    if (on1) row_times_mat6(ka, sm.u.fac.M0[j], xk);
+    __syncthreads();                          // B, D0 consumed
     if (valid) {
       const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
       // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0]
-      double l0[6], y0[6];
-      {
-        double cr[3];
-        const double q1[3] = {x1[3], x1[4], x1[5]};
-        cross3(q1, r0, cr);
-        l0[0] = x1[3]; l0[1] = x1[4]; l0[2] = x1[5];
-        l0[3] = x1[0] - cr[0]; l0[4] = x1[1] - cr[1]; l0[5] = x1[2] - cr[2];
-        const double q0[3] = {x0[3], x0[4], x0[5]};
-        cross3(q0, r0, cr);
-        y0[0] = x0[3]; y0[1] = x0[4]; y0[2] = x0[5];
-        y0[3] = x0[0] - cr[0]; y0[4] = x0[1] - cr[1]; y0[5] = x0[2] - cr[2];
-      }
+      double w0[6], cr[3];
+      const double q1[3] = {xk[3], xk[4], xk[5]};
+      cross3(q1, r0, cr);
+      w0[0] = xk[3]; w0[1] = xk[4]; w0[2] = xk[5];
+      w0[3] = xk[0] - cr[0]; w0[4] = xk[1] - cr[1]; w0[5] = xk[2] - cr[2];
+      if (hf == 0) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        sm.LG[0][j][c][b][0] = (float)l0[b];
-        sm.u.fac.M2[j][c][b] = l0[b];           // L_0 rows for F
-        sm.u.fac.M0[j][c][b] = y0[b];           // Ka^-1 D0 W_0^-1 rows for L_1
+        for (int b = 0; b < 6; ++b) {
+          sm.LG[0][j][c][b][0] = (float)w0[b];
+          sm.u.fac.M2[j][c][b] = w0[b];         // L_0 rows for F
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) sm.u.fac.M0[j][c][b] = w0[b];   // Ka^-1 D0 W_0^-1 rows for L_1
       }
     }
-    wg_sync<NT>();
-    if (valid) {
-      double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    __syncthreads();
+    double fv64[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // row c of F (lane 0)
+    if (on0) {
+      row_times_mat6(urow, sm.u.fac.M2[j], fv64);     // F = U L_0
 #pragma unroll
-      for (int b = 0; b < 6; ++b) fv64[b] = 0.0;
-      row_times_mat6(Trow, sm.u.fac.M0[j], sl);     // L_1 = T (Ka^-1 D0 W_0^-1)
-      row_times_mat6(urow, sm.u.fac.M2[j], fv64);   // F = U L_0
-      row_times_mat6(Trow, sm.u.fac.M1[j], sk);     // T Ka^-1
+      for (int b = 0; b < 6; ++b) sm.KG[0][j][c][b][0] = (float)ka[b];
+    }
+    if (on1) {
+      double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      row_times_mat6(Trow, sm.u.fac.M0[j], sl);       // L_1 = T (Ka^-1 D0 W_0^-1)
+      row_times_mat6(Trow, sm.u.fac.M1[j], sk);       // T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
         sm.LG[1][j][c][b][0] = (float)sl[b];
         // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
-        sm.KG[0][j][c][b][0] = (float)ka[0][b];
         sm.KG[1][j][c][b][0] = (float)sk[b];
       }
     }
-    wg_sync<NT>();
+    __syncthreads();
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
+      float gr[6];                             // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        float gr[6];                           // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
+      for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[c][b] - ((b == 2 && c < 4) ? muf : 0.f);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[c][b] - ((b == 2 && co < 4) ? muf[f] : 0.f);
+      for (int i = 0; i < 6; ++i) {
+        float gk = 0.f, gl = 0.f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          float gk = 0.f, gl = 0.f;
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            gk = fmaf(gr[b], sm.KG[f][j][b][i][0], gk);
-            gl = fmaf(gr[b], sm.LG[f][j][b][i][0], gl);
-          }
-          sm.KG[f][j][c][i][1] = gk;
-          sm.LG[f][j][c][i][1] = gl;
+        for (int b = 0; b < 6; ++b) {
+          gk = fmaf(gr[b], sm.KG[f][j][b][i][0], gk);
+          gl = fmaf(gr[b], sm.LG[f][j][b][i][0], gl);
         }
+        sm.KG[f][j][c][i][1] = gk;
+        sm.LG[f][j][c][i][1] = gl;
       }
     }
     if (dbg.prof) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
+    // K' row half = Gt row half + F row on the own step, scaled to unit diagonal (S K' S, S = diag(K')^-1/2:
+    // every pivot of the sweep is then <= 1, which the pivot-row update below relies on).
+    float fv[6];
 #pragma unroll
-    for (int q = 0; q < 3 * H; ++q) unpark(Grow[q], gpark[q]);
-    // K' row = Gt row + F row on the own step; then symmetric sweep with a rotating register file:
-    // at step k register r holds column (r + k) mod NW, so the pivot column is always register 0.
-    if (valid) {
+    for (int b = 0; b < 6; ++b) {
+      fv[b] = (float)fv64[b];
+      const float o = pair_swap(fv[b]);
+      fv[b] = hf == 0 ? fv[b] : o;
+    }
+    {
+      float fd = 0.f;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const int j2 = q / 6, b = q % 6;
-        float v;
-        if (c < 3) v = (b < 3) ? Grow[(b < 3 ? b : 0) * H + j2] : 0.f;
-        else v = (b < 3) ? 0.f : Grow[(b < 3 ? 0 : b - 3) * H + j2];   // zero unless b == c
-        VROW(q) = v;
-      }
-      float fv[6];
+      for (int b = 0; b < 6; ++b) fd = fmaf((float)mkd[b], fv[b], fd);
+      dsc = valid ? rsq_approx(gdiag + fd) : 1.f;
+    }
+    if (on0) sm.dsc[slot<H>(row)] = dsc;
 #pragma unroll
-      for (int b = 0; b < 6; ++b) fv[b] = (float)fv64[b];
+    for (int q = 0; q < HN; ++q) {
+      const int jj = q / 6, b = q % 6;
+      float v;
+      if (c < 3) v = (b < 3) ? Grow[(b < 3 ? b : 0) * HH + jj] : 0.f;
+      else v = (b < 3) ? 0.f : Grow[(b < 3 ? 0 : b - 3) * HH + jj];   // zero unless b == c
+      VROW(q) = v;
+    }
 #pragma unroll
-      for (int j2 = 0; j2 < H; ++j2) {
-        const float mj = (j2 == j) ? 1.f : 0.f;
+    for (int jj = 0; jj < HH; ++jj) {
+      const float mj = (jb + jj == j) ? 1.f : 0.f;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) VROW(6 * j2 + b) = fmaf(mj, fv[b], VROW(6 * j2 + b));
+      for (int b = 0; b < 6; ++b) VROW(6 * jj + b) = fmaf(mj, fv[b], VROW(6 * jj + b));
+    }
+    __syncthreads();
+    {
+      const f2 d2 = {dsc, dsc};
+#pragma unroll
+      for (int q = 0; q < HN; q += 4) {
+        if (q + 4 <= HN) {
+          const float4 s4 = *reinterpret_cast<const float4*>(&sm.dsc[hf * HNP + q]);
+          Vr[q / 2] = Vr[q / 2] * d2 * f2{s4.x, s4.y};
+          Vr[q / 2 + 1] = Vr[q / 2 + 1] * d2 * f2{s4.z, s4.w};
+        } else {
+          const float2 s2 = *reinterpret_cast<const float2*>(&sm.dsc[hf * HNP + q]);
+          Vr[q / 2] = Vr[q / 2] * d2 * f2{s2.x, s2.y};
+        }
       }
     }
-    // Groups of U steps are unrolled so the pivot column sits in the static register u; the register
-    // file is rotated by U once per group.  Pivot lane: row = column / p; other lanes: row -= (a_ik/p) * pivot row.
+    // Symmetric sweep with a rotating register file: at group k0 register i of half hf holds column
+    // (k0 + hf HN + i) mod NW, so the pivot column is always a static register of the half-0 lanes.  Per pivot:
+    // the half-0 lanes publish their entry of the pivot column (= pivot row, by symmetry), every lane fetches
+    // the HN entries of its half and updates with ONE packed FMA per pair: row -= t * pivot row, with
+    // t = a_ik / p for the other rows and t = 1 - 1/p for the pivot row itself (row_k - (1 - 1/p) row_k =
+    // row_k / p: exact up to rounding because p <= 1 after the scaling; no second multiply, and the row is
+    // never rebuilt from the column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
     constexpr int U = 6;
-    static_assert(NW % U == 0 && U % 2 == 0, "sweep group must divide 6H and be even");
+    static_assert(NW % U == 0 && U % 2 == 0 && U <= HN, "sweep group must divide 6H and be even");
 #pragma unroll 1
-    // The idle lanes of the last wave run the sweep too (no exec-mask juggling per pivot): they publish
-    // into slots nobody reads and update a row nobody uses.
     for (int k0 = 0; k0 < NW; k0 += U) {
+      int pos = row - k0;                       // rotated index of the own row
+      pos += (pos < 0) ? NW : 0;
+      const int ps = valid ? slot<H>(pos) : 0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float* buf = sm.piv[u & 1];
-        {
-          int pos = l - k0;
-          pos += (pos < 0) ? NW : 0;
-          buf[valid ? pos : l] = VROW(u);
-        }
-        wg_sync<NT>();
-        {
-          // fetch the pivot vector first (back-to-back ds_read_b128, one wait), then compute: with one
-          // wave per SIMD nothing else hides the LDS latency.  (Chunked fetch costs less registers.)
-#ifdef BMPC_PIVOT_CHUNKS                     // for builds that target two waves per SIMD (256 registers)
-          constexpr int PB = (NW % 24 == 0) ? 24 : 20;
-#else
-          constexpr int PB = NW;
-#endif
-          static_assert(NW % PB == 0 && PB % 4 == 0 && U <= PB, "pivot chunk");
-          const float ci = VROW(u);
-          const bool isp = (l == k0 + u);
-          // the pivot lane rebuilds its row from the published COLUMN (buf), which re-symmetrises the
-          // matrix at every pivot; scaling its own row instead lets f32 asymmetry grow and diverge
-          const float sc = isp ? 0.f : 1.f;
-          f2 t2 = {0.f, 0.f};
-          const f2 sc2 = {sc, sc};
-          float t = 0.f;
+        if (on0) buf[ps] = VROW(u);
+        __syncthreads();
+        const float ci = buf[ps];
+        const float pinv = rcp_approx(buf[u]);
+        const bool isp = (row == k0 + u);
+        const float t = isp ? 1.f - pinv : ci * pinv;
+        const f2 t2 = {-t, -t};
 #pragma unroll
-          for (int r0 = 0; r0 < NW; r0 += PB) {
-            f2 pb[PB / 2];
-#pragma unroll
-            for (int r = 0; r < PB; r += 4) {
-              const float4 q4 = *reinterpret_cast<const float4*>(&buf[r0 + r]);
-              pb[r / 2] = f2{q4.x, q4.y};
-              pb[r / 2 + 1] = f2{q4.z, q4.w};
-            }
-            if (r0 == 0) {
-              const float pinv = __builtin_amdgcn_rcpf(pb[u >> 1][u & 1]);
-              t = isp ? -pinv : ci * pinv;
-              t2 = f2{t, t};
-            }
-#pragma unroll
-            for (int r = 0; r < PB / 2; ++r)
-              Vr[r0 / 2 + r] = __builtin_elementwise_fma(-t2, pb[r], sc2 * Vr[r0 / 2 + r]);
+        for (int q = 0; q < HN; q += 4) {
+          if (q + 4 <= HN) {
+            const float4 p4 = *reinterpret_cast<const float4*>(&buf[hf * HNP + q]);
+            Vr[q / 2] = __builtin_elementwise_fma(t2, f2{p4.x, p4.y}, Vr[q / 2]);
+            Vr[q / 2 + 1] = __builtin_elementwise_fma(t2, f2{p4.z, p4.w}, Vr[q / 2 + 1]);
+          } else {
+            const float2 p2 = *reinterpret_cast<const float2*>(&buf[hf * HNP + q]);
+            Vr[q / 2] = __builtin_elementwise_fma(t2, f2{p2.x, p2.y}, Vr[q / 2]);
           }
-          VROW(u) = t;
         }
+        if (hf == 0) VROW(u) = isp ? -pinv : t;
       }
-      {                                        // rotate left by U
+      {                                        // rotate left by U across the pair
         f2 tmp[U / 2];
 #pragma unroll
-        for (int u = 0; u < U / 2; ++u) tmp[u] = Vr[u];
+        for (int u = 0; u < U / 2; ++u) tmp[u] = pair_swap(Vr[u]);
 #pragma unroll
-        for (int r = 0; r + U / 2 < NW / 2; ++r) Vr[r] = Vr[r + U / 2];
+        for (int r = 0; r + U / 2 < HN / 2; ++r) Vr[r] = Vr[r + U / 2];
 #pragma unroll
-        for (int u = 0; u < U / 2; ++u) Vr[NW / 2 - U / 2 + u] = tmp[u];
+        for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
       }
     }
     if (dbg.prof) t_sweep += clock64() - t_mark;
@@ -882,15 +851,16 @@ solve_kernel(const DevParams P, const int B,
   bool need_factor = true;
 
   // ------------------------------------------------------------------ E. ADMM iterations
-  // A lane carries, next to its variables and rows, two products of the iterate that are linear in
+  // A lane carries, next to its variable and rows, two products of the iterate that are linear in
   // it and so follow the relaxation x <- alpha x~ + (1 - alpha) x without an exchange:
-  //   axg_f = (G_f x_f)[c]   : x~ = x - d with d_f = N_f Ka^-1 N' r + L_f gamma, so G_f x~ = axg - (GK tn + GL gamma)
-  //   bwl   = (W x)[l]       : W N = 0 and W L = sum_f W_f D_f^-1 W_f' F = I, so W x~ = bw - gamma exactly
+  //   axg = (G_f x_f)[c]     : x~ = x - d with d_f = N_f Ka^-1 N' r + L_f gamma, so G_f x~ = axg - (GK tn + GL gamma)
+  //   gbl = (Gt W x + qt)[row]: W N = 0 and W L = sum_f W_f D_f^-1 W_f' F = I, so W x~ = W x - gamma exactly and
+  //                            gb~ = gb - Gt gamma (both lanes of the pair carry the full value)
   // The f32 rounding of these corrections vanishes with the step (r, gamma -> 0) and both carried values
-  // are rebuilt exactly from x at every stopping test, so the fixed point is unchanged.
-  RT xo[2] = {0, 0};                          // own variables
-  RT zb[2] = {0, 0}, zg[2] = {0, 0}, yb[2] = {0, 0}, yg[2] = {0, 0};
-  RT axg[2] = {0, 0}, bwl = 0, gbl = qt;     // x = 0: b = 0, gb = qt
+  // are rebuilt exactly from x at every second stopping test, so the fixed point is unchanged.
+  RT xo = 0;                                  // own variable
+  RT zb = 0, zg = 0, yb = 0, yg = 0;
+  RT axg = 0, bwl = 0, gbl = qt;              // x = 0: b = 0, gb = qt
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
@@ -900,25 +870,24 @@ solve_kernel(const DevParams P, const int B,
   while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
   float res_p = 0.f, res_s = 0.f;
 
-  // exact axg, bwl from x (exchange through LDS); all threads call
+  // exact axg, bwl, gbl from x (exchange through LDS); all threads call
   auto refresh = [&]() {
-    if (valid) { sm.xs[j][0][c] = xo[0]; sm.xs[j][1][c] = xo[1]; }
-    wg_sync<NT>();
+    if (valid) sm.xs[j][f][c] = xo;
+    __syncthreads();
     if (valid) {
       RT xblk[2][6], gu[6];
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) xblk[f][b] = sm.xs[j][f][b];
+        for (int b = 0; b < 6; ++b) xblk[ft][b] = sm.xs[j][ft][b];
 #pragma unroll
       for (int b = 0; b < 6; ++b) gu[b] = sm.Gu[c][b];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
+      {
         RT a = 0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) a += gu[b] * xblk[f][b];
+        for (int b = 0; b < 6; ++b) a += gu[b] * (f == 0 ? xblk[0][b] : xblk[1][b]);
         const RT negmu = c < 4 ? -(RT)sm.muf[j][f] : (RT)0;
-        axg[f] = a + negmu * xblk[f][2];
+        axg = a + negmu * (f == 0 ? xblk[0][2] : xblk[1][2]);
       }
       if (c < 3) {
         RT t0[3], t1[3];
@@ -933,75 +902,45 @@ solve_kernel(const DevParams P, const int B,
         RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
         bwl = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
       }
-      sm.u.itv.bwT[c][j] = bwl;
+      if (hf == 0) sm.u.itv.bwT[c][j] = bwl;
     }
-    wg_sync<NT>();
+    __syncthreads();
+    RT gpart = 0;
     if (valid) {
-      // gbl = (Gt b + qt)[l] in f64: 3 H doubles of the lane's component group, 3 independent chains
-      static_assert(H % 2 == 0, "the wrench is read in groups of 6");
+      // (Gt b)[row] over the own column half in f64: 3 HH doubles of the lane's component group
       const RT* bsrc = &sm.u.itv.bwT[c < 3 ? 0 : 3][0];
-      RT g0 = qt, g1 = 0, g2 = 0;
+      RT g0 = 0, g1 = 0, g2 = 0;
 #pragma unroll
-      for (int q = 0; q < 3 * H; q += 6) {
-        RT v[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = bsrc[q + k];
-        g0 += (RT)Grow[q] * v[0];     g1 += (RT)Grow[q + 1] * v[1]; g2 += (RT)Grow[q + 2] * v[2];
-        g0 += (RT)Grow[q + 3] * v[3]; g1 += (RT)Grow[q + 4] * v[4]; g2 += (RT)Grow[q + 5] * v[5];
+      for (int jj = 0; jj < HH; ++jj) {
+        g0 += (RT)Grow[jj] * bsrc[jb + jj];
+        g1 += (RT)Grow[HH + jj] * bsrc[H + jb + jj];
+        g2 += (RT)Grow[2 * HH + jj] * bsrc[2 * H + jb + jj];
       }
-      gbl = g0 + (g1 + g2);
+      gpart = g0 + (g1 + g2);
     }
+    gpart += pair_swap(gpart);
+    gbl = gpart + qt;
   };
 
 #pragma unroll 1
   for (it = 0; it < P.max_iter;) {
     if (need_factor) {                         // workgroup-uniform
-      // park what the factorisation does not touch (see park() above)
-      Parked64 pk[29];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        park(xo[f], pk[f]); park(zb[f], pk[2 + f]); park(zg[f], pk[4 + f]); park(yb[f], pk[6 + f]);
-        park(yg[f], pk[8 + f]); park(axg[f], pk[10 + f]); park(irvb[f], pk[12 + f]); park(irvg[f], pk[14 + f]);
-        park(lb[f], pk[16 + f]); park(ub[f], pk[18 + f]); park(cmu[f], pk[20 + f]);
-      }
-      park(gbl, pk[22]); park(qt, pk[23]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) park(mk3[k], pk[24 + k]);
-      float pkd[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) park(drf[k], pkd[k]);
-#pragma unroll
-      for (int q = 0; q < 3 * H; ++q) park(Grow[q], gpark[q]);
       factor();
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        unpark(xo[f], pk[f]); unpark(zb[f], pk[2 + f]); unpark(zg[f], pk[4 + f]); unpark(yb[f], pk[6 + f]);
-        unpark(yg[f], pk[8 + f]); unpark(axg[f], pk[10 + f]); unpark(irvb[f], pk[12 + f]); unpark(irvg[f], pk[14 + f]);
-        unpark(lb[f], pk[16 + f]); unpark(ub[f], pk[18 + f]); unpark(cmu[f], pk[20 + f]);
-      }
-      unpark(gbl, pk[22]); unpark(qt, pk[23]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) unpark(mk3[k], pk[24 + k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) unpark(drf[k], pkd[k]);
       ++nfac;
       need_factor = false;
     }
     if (dbg.prof) t_last = clock64();
-    // --- P0: row residuals w = y + rho (A x - z); publish them and the net wrench
-    RT wb[2];
+    // --- P0: row residuals w = y + rho (A x - z); publish them and the gradient
+    RT wb = 0;
     if (valid) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        wb[f] = yb[f] + rvb[f] * (xo[f] - zb[f]);
-        sm.u.itv.wg[j][f][c] = yg[f] + rvg[f] * (axg[f] - zg[f]);
-      }
-      sm.u.itv.gb[l] = gbl;
+      wb = yb + rvb * (xo - zb);
+      sm.u.itv.wg[j][f][c] = yg + rvg * (axg - zg);
+      if (hf == 0) sm.u.itv.gb[row] = gbl;
     }
-    wg_sync<NT>();
+    __syncthreads();
     BMPC_STAMP(0)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
-    float lcol[2][6];
+    float lcol[6];
     if (valid) {
       RT gut[6];
 #pragma unroll
@@ -1013,71 +952,80 @@ solve_kernel(const DevParams P, const int B,
       const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
       const RT g1 = sm.u.itv.gb[6 * j + i1], g2 = sm.u.itv.gb[6 * j + i2];
       const RT gsel = sm.u.itv.gb[6 * j + (c < 3 ? c + 3 : c - 3)];
+      RT r = R2v * xo + wb;
+      RT wq[6];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        RT r = R2v[f] * xo[f] + wb[f];
-        RT wq[6];
+      for (int q = 0; q < 6; ++q) wq[q] = sm.u.itv.wg[j][f][q];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) wq[q] = sm.u.itv.wg[j][f][q];
+      for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
+      r += cmu * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
+      const RT wt = g1 * sm.rx[j][f][c][0] - g2 * sm.rx[j][f][c][1] + gsel;
+      sm.u.itv.r32[j][f][c] = (float)(r + wt);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
-        r += cmu[f] * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
-        const RT wt = g1 * sm.rx[j][f][c][0] - g2 * sm.rx[j][f][c][1] + gsel;
-        sm.u.itv.r32[j][f][c] = (float)(r + wt);
-      }
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) lcol[f][i] = sm.LG[f][j][i][c][0];
+      for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f][j][i][c][0];
     }
-    wg_sync<NT>();
+    __syncthreads();
     BMPC_STAMP(2)
-    // --- P3: beta = L' r
+    // --- P3: beta = L' r (own foot's part, summed over the pair), published scaled
     float rj[2][6];
+    float bsum = 0.f;
     if (valid) {
-      float s = 0.f;
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          rj[f][i] = sm.u.itv.r32[j][f][i];
-          s = fmaf(lcol[f][i], rj[f][i], s);
+        for (int i = 0; i < 6; i += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(&sm.u.itv.r32[j][ft][i]);
+          rj[ft][i] = v.x; rj[ft][i + 1] = v.y;
         }
-      sm.u.itv.beta[l] = s;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bsum = fmaf(lcol[i], f == 0 ? rj[0][i] : rj[1][i], bsum);
     }
-    wg_sync<NT>();
+    bsum += pair_swap(bsum);
+    if (valid && hf == 0) sm.u.itv.beta[slot<H>(row)] = bsum * dsc;
+    __syncthreads();
     BMPC_STAMP(3)
-    // --- P4: gamma = V beta   (Vr holds -V)
-    float gown = 0.f;
-    f2 kg[2][6], lg[2][6];                             // rows c of {Kn, G Kn} and {L, G L} for P5
-    if (valid) {
+    // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S)
+    float gown;
+    {
       f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < NW; q += 4) {
-        const float4 bq = *reinterpret_cast<const float4*>(&sm.u.itv.beta[q]);
-        a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
-        a1 = __builtin_elementwise_fma(Vr[q / 2 + 1], f2{bq.z, bq.w}, a1);
+      for (int q = 0; q < HN; q += 4) {
+        if (q + 4 <= HN) {
+          const float4 bq = *reinterpret_cast<const float4*>(&sm.u.itv.beta[hf * HNP + q]);
+          a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+          a1 = __builtin_elementwise_fma(Vr[q / 2 + 1], f2{bq.z, bq.w}, a1);
+        } else {
+          const float2 bq = *reinterpret_cast<const float2*>(&sm.u.itv.beta[hf * HNP + q]);
+          a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+        }
       }
-      gown = -((a0.x + a0.y) + (a1.x + a1.y));
-      sm.u.itv.gam[l] = gown;
-      sm.u.itv.gamT[c < 3 ? 0 : 1][(c < 3 ? c : c - 3) * H + j] = gown;
+      float part = (a0.x + a0.y) + (a1.x + a1.y);
+      part += pair_swap(part);
+      gown = -part * dsc;
     }
-    wg_sync<NT>();
+    if (valid) {
+      if (hf == 0) sm.u.itv.gam[row] = gown;
+      else sm.u.itv.gamT[(c < 3 ? 0 : 2) + (j >= HH ? 1 : 0)][(c < 3 ? c : c - 3) * HH + (j >= HH ? j - HH : j)] = gown;
+    }
+    __syncthreads();
     BMPC_STAMP(4)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
     const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
+    float ginc = 0.f;
     if (valid) {
       float gm[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) gm[i] = sm.u.itv.gam[6 * j + i];
+      for (int i = 0; i < 6; i += 2) {
+        const float2 v = *reinterpret_cast<const float2*>(&sm.u.itv.gam[6 * j + i]);
+        gm[i] = v.x; gm[i + 1] = v.y;
+      }
+      f2 kg[6], lg[6];                         // rows c of {Kn, G Kn} and {L, G L} of the own foot
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          kg[f][i] = *reinterpret_cast<const f2*>(&sm.KG[f][j][c][i][0]);
-          lg[f][i] = *reinterpret_cast<const f2*>(&sm.LG[f][j][c][i][0]);
-        }
+      for (int i = 0; i < 6; ++i) {
+        kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f][j][c][i][0]);
+        lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f][j][c][i][0]);
+      }
       // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
       float tn[6];
       {
@@ -1089,71 +1037,64 @@ solve_kernel(const DevParams P, const int B,
         tn[4] = rj[0][4] - rj[1][4];
         tn[5] = rj[0][5] - rj[1][5];
       }
-      RT st_pb[2], st_pg[2], st_x[2], st_g[2], st_dx[2];     // residual statistics inputs (used at stopping tests)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
+      RT st_pb, st_pg, st_x, st_g, st_dx;     // residual statistics inputs (used at stopping tests)
+      {
         f2 dd = {0.f, 0.f};                     // {d_f[c], (G_f d_f)[c]}
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(kg[f][i], f2{tn[i], tn[i]}, dd);
+        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(kg[i], f2{tn[i], tn[i]}, dd);
         if (f == 1) dd = -dd;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(lg[f][i], f2{gm[i], gm[i]}, dd);
+        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(lg[i], f2{gm[i], gm[i]}, dd);
         const float s = dd.x, sg = dd.y;
-        const RT xto = xo[f] - (RT)s;
-        const RT ztg = axg[f] - (RT)sg;
+        const RT xto = xo - (RT)s;
+        const RT ztg = axg - (RT)sg;
         const RT ztb = xto;
         // box row
         {
-          const RT zr = alpha * ztb + (1 - alpha) * zb[f];
-          const RT cand = zr + yb[f] * irvb[f];
-          const RT zn = min_rt(max_rt(cand, lb[f]), ub[f]);
-          yb[f] += rvb[f] * (zr - zn);
-          zb[f] = zn;
-          st_pb[f] = ztb - zn;
+          const RT zr = alpha * ztb + (1 - alpha) * zb;
+          const RT cand = zr + yb * irvb;
+          const RT zn = fmin(fmax(cand, lb), ub);
+          yb += rvb * (zr - zn);
+          zb = zn;
+          st_pb = ztb - zn;
         }
         // general row: l = -inf, u = 0
         {
-          const RT zr = alpha * ztg + (1 - alpha) * zg[f];
-          const RT cand = zr + yg[f] * irvg[f];
-          const RT zn = min_rt(cand, (RT)0);
-          yg[f] += rvg[f] * (zr - zn);
-          zg[f] = zn;
-          st_pg[f] = ztg - zn;
+          const RT zr = alpha * ztg + (1 - alpha) * zg;
+          const RT cand = zr + yg * irvg;
+          const RT zn = fmin(cand, (RT)0);
+          yg += rvg * (zr - zn);
+          zg = zn;
+          st_pg = ztg - zn;
         }
-        st_x[f] = xto; st_g[f] = ztg; st_dx[f] = xto - xo[f];
-        xo[f] = alpha * xto + (1 - alpha) * xo[f];
-        axg[f] = alpha * ztg + (1 - alpha) * axg[f];
+        st_x = xto; st_g = ztg; st_dx = xto - xo;
+        xo = alpha * xto + (1 - alpha) * xo;
+        axg = alpha * ztg + (1 - alpha) * axg;
       }
       // gb follows b <- b - alpha gamma: gb -= alpha Gt gamma, the increment in f32 (it vanishes with the step)
       {
-        const float* gsrc = &sm.u.itv.gamT[c < 3 ? 0 : 1][0];
+        const float* gsrc = &sm.u.itv.gamT[(c < 3 ? 0 : 2) + hf][0];
         f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 3 * H; q += 4) {
-          if (q + 4 <= 3 * H) {
-            const float4 g4 = *reinterpret_cast<const float4*>(&gsrc[q]);
-            e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g4.x, g4.y}, e0);
-            e1 = __builtin_elementwise_fma(f2{Grow[q + 2], Grow[q + 3]}, f2{g4.z, g4.w}, e1);
-          } else {
-            const float2 g2 = *reinterpret_cast<const float2*>(&gsrc[q]);
-            e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g2.x, g2.y}, e0);
-          }
+        for (int q = 0; q < GH; q += 4) {
+          const float4 g4 = *reinterpret_cast<const float4*>(&gsrc[q]);
+          e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g4.x, g4.y}, e0);
+          e1 = __builtin_elementwise_fma(f2{Grow[q + 2], Grow[q + 3]}, f2{g4.z, g4.w}, e1);
         }
-        gbl -= alpha * (RT)((e0.x + e0.y) + (e1.x + e1.y));
+        ginc = (e0.x + e0.y) + (e1.x + e1.y);
       }
       if (check_now) {
         // a real (uniform) branch: predicated, this costs ~25 instructions in every iteration
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          rp = fmaxf(rp, fmaxf(fabsf((float)st_pb[f]), fabsf((float)st_pg[f])));
-          nz = fmaxf(nz, fmaxf(fabsf((float)st_x[f]), fabsf((float)st_g[f])));
-          rs = fmaxf(rs, fabsf((float)st_dx[f]));
-          // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
-          nx = (st_x[f] == st_x[f]) ? fmaxf(nx, fabsf((float)st_x[f])) : __builtin_inff();
-        }
+        BMPC_FENCE();
+        rp = fmaxf(fabsf((float)st_pb), fabsf((float)st_pg));
+        nz = fmaxf(fabsf((float)st_x), fabsf((float)st_g));
+        rs = fabsf((float)st_dx);
+        // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
+        nx = (st_x == st_x) ? fabsf((float)st_x) : __builtin_inff();
       }
     }
+    ginc += pair_swap(ginc);
+    gbl -= alpha * (RT)ginc;
     ++it;
     BMPC_STAMP(5)
     // --- stopping test (workgroup-uniform); the carried products are rebuilt from x first
@@ -1176,89 +1117,80 @@ solve_kernel(const DevParams P, const int B,
     if (it == next_adapt) {
       next_adapt += P.adapt_every;
       if (nfac <= P.max_refactor) {
-      int changed = 0;
-      float nb[2], ng[2];
-      // Damping: an instance that is still re-classifying after many rounds is cycling between active sets
-      // (about one in a million at kappa = 20); smaller moves break the cycle (sqrt(kappa) after 10
-      // factorisations, its square root after 16), where stopping the adaptation would leave hundreds of
-      // plain-ADMM iterations.
-      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
-      if (valid) {
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const bool actb = (zb[f] <= lb[f] || zb[f] >= ub[f]) && yb[f] != (RT)0;
-          const bool actg = (zg[f] >= (RT)0) && yg[f] != (RT)0;
+        int changed = 0;
+        float nb = 0.f, ng = 0.f;
+        // Damping: an instance that is still re-classifying after many rounds is cycling between active sets
+        // (about one in a million at kappa = 20); smaller moves break the cycle (sqrt(kappa) after 10
+        // factorisations, its square root after 16), where stopping the adaptation would leave hundreds of
+        // plain-ADMM iterations.
+        const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
+        if (valid) {
+          const bool actb = (zb <= lb || zb >= ub) && yb != (RT)0;
+          const bool actg = (zg >= (RT)0) && yg != (RT)0;
           // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
           const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-          const float ob = (float)rvb[f], og = (float)rvg[f];
-          nb[f] = eqb[f] ? P.rho_eq : (actb ? fminf(ob * kap, hib) : fmaxf(ob / kap, P.rho_lo));
-          ng[f] = actg ? fminf(og * kap, hig) : fmaxf(og / kap, P.rho_lo);
-          changed |= (nb[f] != ob) | (ng[f] != og);
+          const float ob = (float)rvb, og = (float)rvg;
+          nb = eqb ? P.rho_eq : (actb ? fminf(ob * kap, hib) : fmaxf(ob / kap, P.rho_lo));
+          ng = actg ? fminf(og * kap, hig) : fmaxf(og / kap, P.rho_lo);
+          changed = (nb != ob) | (ng != og);
         }
-      }
-      changed = __syncthreads_or(changed);
-      if (changed) {
-        if (valid) {
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            rvb[f] = (RT)nb[f]; rvg[f] = (RT)ng[f];
-            irvb[f] = (RT)1 / rvb[f]; irvg[f] = (RT)1 / rvg[f];
+        changed = __syncthreads_or(changed);
+        if (changed) {
+          if (valid) {
+            rvb = (RT)nb; rvg = (RT)ng;
+            irvb = (RT)1 / rvb; irvg = (RT)1 / rvg;
           }
+          need_factor = true;
         }
-        need_factor = true;
-      }
       }
     }
     BMPC_STAMP(6)
   }
-  if (valid) { sm.xs[j][0][c] = xo[0]; sm.xs[j][1][c] = xo[1]; }   // for the state roll-out below
+  if (valid) sm.xs[j][f][c] = xo;              // for the state roll-out below
 
   // ------------------------------------------------------------------ F. outputs (REF:300-304)
   if (valid) {
     float* uo = controls + ((size_t)inst * H + j) * 12;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
-      uo[pos] = (float)xo[f];
-    }
+    const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
+    uo[pos] = (float)xo;
   }
   if (states) {
     // wrench of the final x (exact: rebuilt at the last stopping test), then X_i = s_i + Gam_t b
-    wg_sync<NT>();
-    if (valid) sm.u.itv.bwT[c][j] = bwl;
-    wg_sync<NT>();
+    __syncthreads();
+    if (valid && hf == 0) sm.u.itv.bwT[c][j] = bwl;
+    __syncthreads();
     if (valid) {
       float* so = states + ((size_t)inst * H + j) * 13;
       const int i = j;
       if (c < 3) {
         const int a = c;
-        // euler: s + sum_{j2 < i} Me[i][j2] tau_j2 ; omega: w_fb + dt sum_{j2 <= i} Iw_j2 tau_j2
-        RT e = sm.s0[i][a], w = sm.s0[i][6 + a];
+        // lane 0: euler = s + sum_{j2 < i} Me[i][j2] tau_j2 ; lane 1: omega = w_fb + dt sum_{j2 <= i} Iw_j2 tau_j2
+        RT e = hf == 0 ? sm.s0[i][a] : sm.s0[i][6 + a];
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
           const RT t3[3] = {sm.u.itv.bwT[0][j2], sm.u.itv.bwT[1][j2], sm.u.itv.bwT[2][j2]};
-          if (j2 < i) {
-            const float* m1 = sm.Me[pair_index(i, j2)];
-            e += (RT)m1[3 * a] * t3[0] + (RT)m1[3 * a + 1] * t3[1] + (RT)m1[3 * a + 2] * t3[2];
+          if (hf == 0) {
+            if (j2 < i) {
+              const float* m1 = sm.Me[pair_index(i, j2)];
+              e += (RT)m1[3 * a] * t3[0] + (RT)m1[3 * a + 1] * t3[1] + (RT)m1[3 * a + 2] * t3[2];
+            }
+          } else {
+            e += dt * (sm.Iw[j2][3 * a] * t3[0] + sm.Iw[j2][3 * a + 1] * t3[1] + sm.Iw[j2][3 * a + 2] * t3[2]);
           }
-          w += dt * (sm.Iw[j2][3 * a] * t3[0] + sm.Iw[j2][3 * a + 1] * t3[1] + sm.Iw[j2][3 * a + 2] * t3[2]);
         }
-        so[a] = (float)e;
-        so[6 + a] = (float)w;
+        so[hf == 0 ? a : 6 + a] = (float)e;
       } else {
         const int a = c - 3;
-        RT p = sm.s0[i][3 + a], v = sm.s0[i][9 + a];
+        RT p = hf == 0 ? sm.s0[i][3 + a] : sm.s0[i][9 + a];
         const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
           const RT fa = sm.u.itv.bwT[3 + a][j2];
-          p += kp * (RT)(i - j2) * fa;
-          v += kvv * fa;
+          p += (hf == 0 ? kp * (RT)(i - j2) : kvv) * fa;
         }
-        so[3 + a] = (float)p;
-        so[9 + a] = (float)v;
+        so[hf == 0 ? 3 + a : 9 + a] = (float)p;
       }
-      if (c == 0) so[12] = 1.0f;
+      if (c == 0 && hf == 0) so[12] = 1.0f;
     }
   }
   if (dbg.prof && l == 0) {

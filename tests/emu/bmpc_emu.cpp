@@ -1,0 +1,153 @@
+// tests/emu/bmpc_emu.cpp -- TEST INFRASTRUCTURE: runs the HIP solve kernel's source on the CPU, one std::thread
+// per lane of a workgroup, so that the kernel's logic (thread map, LDS exchanges, barriers, cross-lane swaps)
+// can be checked against the oracle without a GPU.  Nothing of the product loads this; it is not a CPU path of
+// the library (libbmpc.so has none) and it is orders of magnitude too slow to be one.
+//
+// How: the kernel file is included as plain C++.  __shared__ becomes a function-local static (one image shared
+// by the lane threads; workgroups run one after another), threadIdx / blockIdx are thread-local, __syncthreads
+// is a std::barrier over the workgroup, and the cross-lane operations (pair swap, wave maximum) go through a
+// shared array between two barriers -- which demands what the GPU code must guarantee anyway: every lane of
+// the workgroup reaches every barrier and every cross-lane operation.
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define BMPC_EMU 1
+#define __global__
+#define __device__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct emu_idx { int x; };
+static thread_local emu_idx threadIdx, blockIdx;
+static std::barrier<>* g_bar = nullptr;
+static int g_or[2];
+static int g_swap[1024];
+static unsigned g_red[1024];
+
+static inline void __syncthreads() { g_bar->arrive_and_wait(); }
+static inline int __syncthreads_or(int v) {
+  // two slots so that back-to-back calls cannot race on the reset
+  static thread_local int phase = 0;
+  int* slot = &g_or[phase & 1];
+  __syncthreads();
+  if (v) __atomic_store_n(slot, 1, __ATOMIC_RELAXED);
+  __syncthreads();
+  const int r = __atomic_load_n(slot, __ATOMIC_RELAXED);
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = 0;
+  ++phase;
+  return r;
+}
+static inline long long clock64() { return 0; }
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline int __double2loint(double d) { long long i; std::memcpy(&i, &d, 8); return (int)(i & 0xffffffffLL); }
+static inline int __double2hiint(double d) { long long i; std::memcpy(&i, &d, 8); return (int)(i >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+  const long long i = ((long long)hi << 32) | (unsigned)lo;
+  double d; std::memcpy(&d, &i, 8); return d;
+}
+using std::fma; using std::fmin; using std::fmax;
+
+namespace bmpc {
+static inline double rcp_approx(double x) { return 1.0 / x; }
+static inline float rcp_approx(float x) { return 1.0f / x; }
+static inline float rsq_approx(float x) { return 1.0f / std::sqrt(x); }
+static inline int pair_swap_i(int v) {
+  g_swap[threadIdx.x] = v;
+  __syncthreads();
+  const int r = g_swap[threadIdx.x ^ 1];
+  __syncthreads();
+  return r;
+}
+static inline unsigned wave_umax(unsigned v) {          // maximum over the lane's wave (64 consecutive lanes)
+  g_red[threadIdx.x] = v;
+  __syncthreads();
+  unsigned m = 0;
+  const int w0 = threadIdx.x & ~63;
+  for (int i = 0; i < 64; ++i) m = g_red[w0 + i] > m ? g_red[w0 + i] : m;
+  __syncthreads();
+  return m;
+}
+}  // namespace bmpc
+#define BMPC_FENCE() do { } while (0)
+
+#include "../../biped_mpc_py_amd/csrc/bmpc_kernels.hip"
+#include "bmpc.h"
+
+namespace {
+
+template <int H>
+void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+           const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states, int32_t* iters,
+           float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg) {
+  constexpr int NT = bmpc::Dims<H>::NT;
+  for (int b = 0; b < B; ++b) {
+    std::barrier<> bar(NT);
+    g_bar = &bar;
+    g_or[0] = g_or[1] = 0;
+    std::vector<std::thread> th;
+    th.reserve(NT);
+    for (int t = 0; t < NT; ++t)
+      th.emplace_back([&, t]() {
+        threadIdx.x = t;
+        blockIdx.x = b;
+        bmpc::solve_kernel<H>(P, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg);
+      });
+    for (auto& x : th) x.join();
+  }
+}
+
+// the same mapping as make_dev_params in csrc/bmpc_capi.hip (kept in step by tests/test_emu.py: identical outputs)
+bool inv3(const double* a, double* o) {
+  const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  if (!(std::fabs(det) > 0)) return false;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+  o[3] = c01 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                              const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+                              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor,
+                              double* dbg_x_ref, double* dbg_foot_ref, double* dbg_Gt, double* dbg_qt, int assemble_only) {
+  bmpc::DevParams d;
+  std::memset(&d, 0, sizeof(d));
+  d.h = p->h; d.half = p->half; d.max_iter = p->max_iter; d.check_every = p->check_every;
+  d.adapt_start = p->adapt_start; d.adapt_every = p->adapt_every; d.max_refactor = p->max_refactor;
+  d.dt = p->dt; d.kv = p->kv; d.m = p->m; d.g = p->g; d.mu = p->mu;
+  d.lt = p->lt - 0.01; d.lh = p->lh - 0.02; d.alpha = p->alpha;
+  for (int i = 0; i < 12; ++i) { d.x_cmd[i] = p->x_cmd[i]; d.Q[i] = p->Q[i]; d.R2[i] = 2.0 * p->R[i]; }
+  if (!inv3(p->I, d.Iinv)) return -1;
+  for (int i = 0; i < 3; ++i) {
+    d.f_max[i] = p->f_max[i]; d.f_min[i] = p->f_min[i]; d.tau_max[i] = p->tau_max[i]; d.tau_min[i] = p->tau_min[i];
+  }
+  d.rho = (float)p->rho; d.rho_eq = (float)(p->rho * p->rho_eq_scale); d.rho_lo = (float)p->rho_lo;
+  d.rho_hi_f = (float)p->rho_hi_f; d.rho_hi_m = (float)p->rho_hi_m;
+  d.eps_pri = (float)p->eps_pri; d.eps_dua = (float)p->eps_dua; d.kappa = (float)p->kappa;
+  bmpc::DebugOut dbg = {dbg_x_ref, dbg_foot_ref, dbg_Gt, dbg_qt, nullptr, assemble_only};
+  switch (p->h) {
+    case 10: run_h<10>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg); break;
+    case 16: run_h<16>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg); break;
+    case 20: run_h<20>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg); break;
+    default: return -1;
+  }
+  return 0;
+}
