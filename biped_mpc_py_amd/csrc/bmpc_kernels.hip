@@ -47,7 +47,11 @@ __device__ __forceinline__ float rsq_approx(float x) { return __builtin_amdgcn_r
 // value of the other lane of the pair (lane ^ 1): DPP quad_perm [1, 0, 3, 2].  Call with all lanes active.
 __device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
 #define BMPC_FENCE() asm volatile("" ::: "memory")
+// hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
+// redone there instead of being hoisted into a second, f64, register copy that lives across the loop
+#define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
+__device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
 __device__ __forceinline__ double pair_swap(double v) {
   const int lo = pair_swap_i(__double2loint(v)), hi = pair_swap_i(__double2hiint(v));
@@ -128,7 +132,9 @@ struct alignas(16) Smem {
     IterScratch<H> itv;
   } u;
   RT xs[H][2][6];            // x (relaxed iterate) for the exact rebuilds and the state roll-out
-  alignas(16) float piv[2][Dims<H>::VL];   // sweep pivot column, double buffered, two-half layout
+  // sweep pivot column, double buffered, two-half layout; behind it one dump slot per row: the half-1 lanes,
+  // which hold no pivot-column entry, store there instead of branching around the store
+  alignas(16) float piv[2][Dims<H>::VL + Dims<H>::NW];
   alignas(16) float dsc[Dims<H>::VL];      // Jacobi scaling of the current factorisation
   // block-diagonal part of K^-1.  Foot-major: a lane's row sits at 48 B x row + const.
   // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
@@ -145,6 +151,7 @@ struct alignas(16) Smem {
   float muf[H][2];           // friction coefficient per step and foot
   RT Gu[6][6];               // mu-free part of the general rows of a foot block, and its transpose
   RT GuT[6][6];
+  RT qtl[Dims<H>::NW];       // wrench-space gradient at x = 0 (constant term of gb; only the exact rebuilds read it)
   float eyz[6];              // body y and z axes in the world frame (columns 1, 2 of eul2rotm(x_fb))
   float red[4][Dims<H>::NWV];
 };
@@ -201,6 +208,7 @@ __device__ __forceinline__ void row_times_mat6(const double (&w)[6], const doubl
     }
 #pragma unroll
     for (int b = 0; b < 6; ++b) out[b] = fma(w[q], row[b], out[b]);
+    if (q & 1) BMPC_FENCE();            // at most two rows in flight: the scheduler otherwise hoists all 36 doubles
   }
 }
 
@@ -282,6 +290,11 @@ solve_kernel(const DevParams P, const int B,
 
   const int inst = blockIdx.x;
   if (inst >= B) return;
+#ifdef BMPC_EMU
+  // the emulation poisons the LDS image (all-ones bytes: NaNs) so that a read of an entry nobody wrote shows
+  if (threadIdx.x == 0) std::memset(&sm, 0xFF, sizeof(sm));
+  __syncthreads();
+#endif
   long long t_start = 0, t_setup = 0, t_blocks = 0, t_sweep = 0, t_mark = 0;
   long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #define BMPC_STAMP(k) if (dbg.prof) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
@@ -289,17 +302,17 @@ solve_kernel(const DevParams P, const int B,
   const int l = threadIdx.x;
   const int hf = l & 1;                        // column half of V / Gt, and the foot this lane owns
   const int f = hf;
-  const int row = l >> 1;
-  const bool valid = row < NW;
-  const int j = valid ? row / 6 : 0;
-  const int c = valid ? row % 6 : 0;
+  // The lanes past the last row (8 at h = 10, 16 at h = 20) CLONE the last row: same indices, same data, same
+  // arithmetic, so their LDS writes repeat the real lane's values at the real lane's addresses and nothing has
+  // to be predicated (every `if (lane is real)` would be an exec-mask branch, and the code sinking across such
+  // branches is what blew up the sweep's register pressure); only their global stores are suppressed.
+  const bool real = (l >> 1) < NW;
+  const int row = real ? (l >> 1) : NW - 1;
+  constexpr bool valid = true;
+  const int j = row / 6;
+  const int c = row % 6;
   const int jb = hf * HH;                      // first step of this lane's column half
   const RT dt = (RT)P.dt;
-  // 0/1 masks of this lane's component: runtime picks are done arithmetically (select chains over
-  // register arrays get demoted to scratch by the compiler)
-  RT mk3[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) mk3[k] = (c % 3 == k) ? (RT)1 : (RT)0;
 
   // ------------------------------------------------------------------ A. references, step data
   RT xfb[12], xc[12];
@@ -331,7 +344,7 @@ solve_kernel(const DevParams P, const int B,
       fr[0] = fx; fr[1] = fy; fr[2] = 0; fr[3] = fx; fr[4] = fy; fr[5] = 0;
     }
   }
-  const bool lead = valid && c == 0 && hf == 0;   // one lane per step
+  const bool lead = real && c == 0 && hf == 0;   // one lane per step
   if (lead) {                                  // debug views of the references (tests)
     if (dbg.x_ref) {
 #pragma unroll
@@ -478,7 +491,7 @@ solve_kernel(const DevParams P, const int B,
           const RT gval = 2 * (acc[b * HH + jj] + cnt * sw);
           Grow[b * HH + jj] = (float)gval;
           if (j2 == j && b == a) gdiag = (float)gval;
-          if (dbg.Gt) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = gval;     // fp64 view of the row (tests)
+          if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = gval;     // fp64 view of the row (tests)
         }
       }
     } else {
@@ -495,7 +508,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int a2 = 0; a2 < 3; ++a2) Grow[a2 * HH + jj] = (a2 == a) ? (float)gval : 0.f;
         if (j2 == j) gdiag = (float)gval;
-        if (dbg.Gt) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + 3 + a] = gval;
+        if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + 3 + a] = gval;
       }
       RT s = 0;
 #pragma unroll
@@ -505,7 +518,8 @@ solve_kernel(const DevParams P, const int B,
       }
       qt = 2 * s;
     }
-    if (dbg.qt && hf == 0) dbg.qt[(size_t)inst * NW + row] = (double)qt;
+    if (dbg.qt && hf == 0 && real) dbg.qt[(size_t)inst * NW + row] = (double)qt;
+    sm.qtl[row] = qt;                          // both lanes computed the same sum
   }
   gdiag += pair_swap(gdiag);                   // one lane of the pair holds it, the other 0
   if (dbg.assemble_only) return;
@@ -515,9 +529,10 @@ solve_kernel(const DevParams P, const int B,
   // General rows of a foot block: G = Gu - mu * [rows 0..3, column 2].  Gu (the mu-free part) is the same
   // for every step and foot of the instance and lives in LDS (plus its transpose); a lane keeps only
   // the mu term it needs.
-  RT lb, ub, R2v;
+  // (f32 values, widened at their points of use: as f64 they would hold twice the registers across the loop)
+  float lb, ub, R2v;
   bool eqb;
-  RT cmu;                                     // -mu_f if this lane's variable is f_z (column 2 of the friction rows)
+  float cmu;                                  // -mu_f if this lane's variable is f_z (column 2 of the friction rows)
   float drf[3];                               // r_0 - r_1 of this step
   {
     float ey[3], ez[3];                       // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
@@ -546,11 +561,11 @@ solve_kernel(const DevParams P, const int B,
       const int a = c < 3 ? c : c - 3;
       const float ubf = cont * (float)(c < 3 ? P.f_max[a] : P.tau_max[a]);      // REF:240-249
       const float lbf = cont * (float)(c < 3 ? P.f_min[a] : P.tau_min[a]);
-      ub = (RT)ubf;
-      lb = (RT)lbf;
+      ub = ubf;
+      lb = lbf;
       eqb = lbf == ubf;
-      R2v = (RT)(float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
-      cmu = c == 2 ? (RT)(-muf) : (RT)0;
+      R2v = (float)(c < 3 ? P.R2[3 * f + a] : P.R2[6 + 3 * f + a]);
+      cmu = c == 2 ? -muf : 0.f;
     }
 #pragma unroll
     for (int a2 = 0; a2 < 3; ++a2) drf[a2] = (float)sm.rr[j][0][a2] - (float)sm.rr[j][1][a2];
@@ -563,9 +578,9 @@ solve_kernel(const DevParams P, const int B,
   }
 
   // ------------------------------------------------------------------ D. factor: L, Kn (and their G images), V for penalties rv
-  RT rvb, rvg;                                // penalties of this lane's box row / general row (f32 values)
-  rvb = (RT)(eqb ? P.rho_eq : P.rho); rvg = (RT)P.rho;
-  RT irvb = (RT)1 / rvb, irvg = (RT)1 / rvg;  // reciprocals (refreshed with the penalties)
+  float rvb, rvg;                             // penalties of this lane's box row / general row
+  rvb = eqb ? P.rho_eq : P.rho; rvg = P.rho;
+  RT irvb = (RT)1 / (RT)rvb, irvg = (RT)1 / (RT)rvg;  // reciprocals (refreshed with the penalties)
   // Half a row of -(S (Gt + F) S)^-1 after the sweep (S = Jacobi scaling to unit diagonal), as float pairs:
   // the sweep and the V mat-vec run on the packed-f32 pipe (v_pk_fma_f32: two f32 per lane and instruction)
   f2 Vr[HN / 2];
@@ -575,11 +590,15 @@ solve_kernel(const DevParams P, const int B,
   auto factor = [&]() {
     if (dbg.prof) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
-    if (valid) sm.rvg[j][f][c] = (float)rvg;
+    if (valid) sm.rvg[j][f][c] = rvg;
     __syncthreads();
+    // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so that
+    // none of it is hoisted out of the iteration loop (= holds registers during the iterations)
+    int co = c;
+    BMPC_OPAQUE(co);
     double mkd[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) mkd[k] = (c == k) ? 1.0 : 0.0;
+    for (int k = 0; k < 6; ++k) mkd[k] = (co == k) ? 1.0 : 0.0;
     const float lh = (float)P.lh, lt = (float)P.lt;
     float ey[3], ez[3], rf[2][3];
 #pragma unroll
@@ -617,7 +636,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         // column c of G_f from the mu-free table; the friction rows' f_z entry is -mu_f
-        const double gc = (double)sm.GuT[c][r] - ((c == 2 && r < 4) ? (double)muf : 0.0);
+        const double gc = (double)sm.GuT[co][r] - ((co == 2 && r < 4) ? (double)muf : 0.0);
         wc[r] = (double)sm.rvg[j][f][r] * gc;
       }
 #pragma unroll
@@ -738,7 +757,7 @@ solve_kernel(const DevParams P, const int B,
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
       float gr[6];                             // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
 #pragma unroll
-      for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[c][b] - ((b == 2 && c < 4) ? muf : 0.f);
+      for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[co][b] - ((b == 2 && co < 4) ? muf : 0.f);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         float gk = 0.f, gl = 0.f;
@@ -765,9 +784,9 @@ solve_kernel(const DevParams P, const int B,
       float fd = 0.f;
 #pragma unroll
       for (int b = 0; b < 6; ++b) fd = fmaf((float)mkd[b], fv[b], fd);
-      dsc = valid ? rsq_approx(gdiag + fd) : 1.f;
+      dsc = rsq_approx(gdiag + fd);
     }
-    if (on0) sm.dsc[slot<H>(row)] = dsc;
+    sm.dsc[slot<H>(row)] = dsc;                 // both lanes of the pair: same value
 #pragma unroll
     for (int q = 0; q < HN; ++q) {
       const int jj = q / 6, b = q % 6;
@@ -810,11 +829,12 @@ solve_kernel(const DevParams P, const int B,
     for (int k0 = 0; k0 < NW; k0 += U) {
       int pos = row - k0;                       // rotated index of the own row
       pos += (pos < 0) ? NW : 0;
-      const int ps = valid ? slot<H>(pos) : 0;
+      const int ps = slot<H>(pos);
+      const int ws = hf == 0 ? ps : Dims<H>::VL + row;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float* buf = sm.piv[u & 1];
-        if (on0) buf[ps] = VROW(u);
+        buf[ws] = VROW(u);
         __syncthreads();
         const float ci = buf[ps];
         const float pinv = rcp_approx(buf[u]);
@@ -831,6 +851,7 @@ solve_kernel(const DevParams P, const int B,
             const float2 p2 = *reinterpret_cast<const float2*>(&buf[hf * HNP + q]);
             Vr[q / 2] = __builtin_elementwise_fma(t2, f2{p2.x, p2.y}, Vr[q / 2]);
           }
+          if (HN > 32 && q % 16 == 12) BMPC_FENCE();   // long rows: the pivot row is fetched in chunks of 16
         }
         if (hf == 0) VROW(u) = isp ? -pinv : t;
       }
@@ -860,7 +881,7 @@ solve_kernel(const DevParams P, const int B,
   // are rebuilt exactly from x at every second stopping test, so the fixed point is unchanged.
   RT xo = 0;                                  // own variable
   RT zb = 0, zg = 0, yb = 0, yg = 0;
-  RT axg = 0, bwl = 0, gbl = qt;              // x = 0: b = 0, gb = qt
+  RT axg = 0, gbl = qt;                       // x = 0: b = 0, gb = qt
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
@@ -889,20 +910,23 @@ solve_kernel(const DevParams P, const int B,
         const RT negmu = c < 4 ? -(RT)sm.muf[j][f] : (RT)0;
         axg = a + negmu * (f == 0 ? xblk[0][2] : xblk[1][2]);
       }
-      if (c < 3) {
-        RT t0[3], t1[3];
-        const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
-        const RT r1[3] = {sm.rr[j][1][0], sm.rr[j][1][1], sm.rr[j][1][2]};
-        cross3(r0, &xblk[0][0], t0);
-        cross3(r1, &xblk[1][0], t1);
-        RT v3[3] = {t0[0] + t1[0] + xblk[0][3] + xblk[1][3], t0[1] + t1[1] + xblk[0][4] + xblk[1][4],
-                    t0[2] + t1[2] + xblk[0][5] + xblk[1][5]};
-        bwl = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
-      } else {
-        RT v3[3] = {xblk[0][0] + xblk[1][0], xblk[0][1] + xblk[1][1], xblk[0][2] + xblk[1][2]};
-        bwl = mk3[0] * v3[0] + mk3[1] * v3[1] + mk3[2] * v3[2];
+      {                                         // net wrench component of this row: (W x)[row] (both lanes: same value)
+        RT v3[3];
+        if (c < 3) {
+          RT t0[3], t1[3];
+          const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
+          const RT r1[3] = {sm.rr[j][1][0], sm.rr[j][1][1], sm.rr[j][1][2]};
+          cross3(r0, &xblk[0][0], t0);
+          cross3(r1, &xblk[1][0], t1);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v3[k] = t0[k] + t1[k] + xblk[0][3 + k] + xblk[1][3 + k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v3[k] = xblk[0][k] + xblk[1][k];
+        }
+        const int c3 = c < 3 ? c : c - 3;
+        sm.u.itv.bwT[c][j] = c3 == 0 ? v3[0] : (c3 == 1 ? v3[1] : v3[2]);
       }
-      if (hf == 0) sm.u.itv.bwT[c][j] = bwl;
     }
     __syncthreads();
     RT gpart = 0;
@@ -919,7 +943,7 @@ solve_kernel(const DevParams P, const int B,
       gpart = g0 + (g1 + g2);
     }
     gpart += pair_swap(gpart);
-    gbl = gpart + qt;
+    gbl = gpart + sm.qtl[row];
   };
 
 #pragma unroll 1
@@ -933,9 +957,9 @@ solve_kernel(const DevParams P, const int B,
     // --- P0: row residuals w = y + rho (A x - z); publish them and the gradient
     RT wb = 0;
     if (valid) {
-      wb = yb + rvb * (xo - zb);
-      sm.u.itv.wg[j][f][c] = yg + rvg * (axg - zg);
-      if (hf == 0) sm.u.itv.gb[row] = gbl;
+      wb = yb + widen(rvb) * (xo - zb);
+      sm.u.itv.wg[j][f][c] = yg + widen(rvg) * (axg - zg);
+      sm.u.itv.gb[row] = gbl;                 // both lanes carry the same value
     }
     __syncthreads();
     BMPC_STAMP(0)
@@ -952,13 +976,13 @@ solve_kernel(const DevParams P, const int B,
       const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
       const RT g1 = sm.u.itv.gb[6 * j + i1], g2 = sm.u.itv.gb[6 * j + i2];
       const RT gsel = sm.u.itv.gb[6 * j + (c < 3 ? c + 3 : c - 3)];
-      RT r = R2v * xo + wb;
+      RT r = widen(R2v) * xo + wb;
       RT wq[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) wq[q] = sm.u.itv.wg[j][f][q];
 #pragma unroll
       for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
-      r += cmu * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
+      r += widen(cmu) * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
       const RT wt = g1 * sm.rx[j][f][c][0] - g2 * sm.rx[j][f][c][1] + gsel;
       sm.u.itv.r32[j][f][c] = (float)(r + wt);
 #pragma unroll
@@ -981,7 +1005,7 @@ solve_kernel(const DevParams P, const int B,
       for (int i = 0; i < 6; ++i) bsum = fmaf(lcol[i], f == 0 ? rj[0][i] : rj[1][i], bsum);
     }
     bsum += pair_swap(bsum);
-    if (valid && hf == 0) sm.u.itv.beta[slot<H>(row)] = bsum * dsc;
+    sm.u.itv.beta[slot<H>(row)] = bsum * dsc;   // both lanes of the pair: same value (a + b == b + a)
     __syncthreads();
     BMPC_STAMP(3)
     // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S)
@@ -998,14 +1022,16 @@ solve_kernel(const DevParams P, const int B,
           const float2 bq = *reinterpret_cast<const float2*>(&sm.u.itv.beta[hf * HNP + q]);
           a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
         }
+        if (HN > 32 && q % 16 == 12) BMPC_FENCE();
       }
       float part = (a0.x + a0.y) + (a1.x + a1.y);
       part += pair_swap(part);
       gown = -part * dsc;
     }
-    if (valid) {
-      if (hf == 0) sm.u.itv.gam[row] = gown;
-      else sm.u.itv.gamT[(c < 3 ? 0 : 2) + (j >= HH ? 1 : 0)][(c < 3 ? c : c - 3) * HH + (j >= HH ? j - HH : j)] = gown;
+    {                                          // lane 0 of the pair: step-major copy, lane 1: the copy for the gradient increment
+      float* gdst = hf == 0 ? &sm.u.itv.gam[row]
+                            : &sm.u.itv.gamT[(c < 3 ? 0 : 2) + (j >= HH ? 1 : 0)][(c < 3 ? c : c - 3) * HH + (j >= HH ? j - HH : j)];
+      *gdst = gown;
     }
     __syncthreads();
     BMPC_STAMP(4)
@@ -1053,8 +1079,8 @@ solve_kernel(const DevParams P, const int B,
         {
           const RT zr = alpha * ztb + (1 - alpha) * zb;
           const RT cand = zr + yb * irvb;
-          const RT zn = fmin(fmax(cand, lb), ub);
-          yb += rvb * (zr - zn);
+          const RT zn = fmin(fmax(cand, widen(lb)), widen(ub));
+          yb += widen(rvb) * (zr - zn);
           zb = zn;
           st_pb = ztb - zn;
         }
@@ -1063,7 +1089,7 @@ solve_kernel(const DevParams P, const int B,
           const RT zr = alpha * ztg + (1 - alpha) * zg;
           const RT cand = zr + yg * irvg;
           const RT zn = fmin(cand, (RT)0);
-          yg += rvg * (zr - zn);
+          yg += widen(rvg) * (zr - zn);
           zg = zn;
           st_pg = ztg - zn;
         }
@@ -1073,15 +1099,24 @@ solve_kernel(const DevParams P, const int B,
       }
       // gb follows b <- b - alpha gamma: gb -= alpha Gt gamma, the increment in f32 (it vanishes with the step)
       {
+        // exactly the 3 HH entries that were written: the padding of gamT is never initialised (and the
+        // factorisation scratch shares its LDS), 0 x garbage could be a NaN
         const float* gsrc = &sm.u.itv.gamT[(c < 3 ? 0 : 2) + hf][0];
         f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+        constexpr int NG = 3 * HH;
 #pragma unroll
-        for (int q = 0; q < GH; q += 4) {
+        for (int q = 0; q + 4 <= NG; q += 4) {
           const float4 g4 = *reinterpret_cast<const float4*>(&gsrc[q]);
           e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g4.x, g4.y}, e0);
           e1 = __builtin_elementwise_fma(f2{Grow[q + 2], Grow[q + 3]}, f2{g4.z, g4.w}, e1);
         }
-        ginc = (e0.x + e0.y) + (e1.x + e1.y);
+        if constexpr (NG % 4 >= 2) {
+          const float2 g2 = *reinterpret_cast<const float2*>(&gsrc[NG / 4 * 4]);
+          e0 = __builtin_elementwise_fma(f2{Grow[NG / 4 * 4], Grow[NG / 4 * 4 + 1]}, f2{g2.x, g2.y}, e0);
+        }
+        float etail = 0.f;
+        if constexpr (NG % 2 == 1) etail = Grow[NG - 1] * gsrc[NG - 1];
+        ginc = ((e0.x + e0.y) + (e1.x + e1.y)) + etail;
       }
       if (check_now) {
         // a real (uniform) branch: predicated, this costs ~25 instructions in every iteration
@@ -1125,11 +1160,11 @@ solve_kernel(const DevParams P, const int B,
         // plain-ADMM iterations.
         const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
         if (valid) {
-          const bool actb = (zb <= lb || zb >= ub) && yb != (RT)0;
+          const bool actb = (zb <= (RT)lb || zb >= (RT)ub) && yb != (RT)0;
           const bool actg = (zg >= (RT)0) && yg != (RT)0;
           // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
           const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-          const float ob = (float)rvb, og = (float)rvg;
+          const float ob = rvb, og = rvg;
           nb = eqb ? P.rho_eq : (actb ? fminf(ob * kap, hib) : fmaxf(ob / kap, P.rho_lo));
           ng = actg ? fminf(og * kap, hig) : fmaxf(og / kap, P.rho_lo);
           changed = (nb != ob) | (ng != og);
@@ -1137,8 +1172,8 @@ solve_kernel(const DevParams P, const int B,
         changed = __syncthreads_or(changed);
         if (changed) {
           if (valid) {
-            rvb = (RT)nb; rvg = (RT)ng;
-            irvb = (RT)1 / rvb; irvg = (RT)1 / rvg;
+            rvb = nb; rvg = ng;
+            irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
           }
           need_factor = true;
         }
@@ -1149,17 +1184,15 @@ solve_kernel(const DevParams P, const int B,
   if (valid) sm.xs[j][f][c] = xo;              // for the state roll-out below
 
   // ------------------------------------------------------------------ F. outputs (REF:300-304)
-  if (valid) {
+  if (real) {
     float* uo = controls + ((size_t)inst * H + j) * 12;
     const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
     uo[pos] = (float)xo;
   }
   if (states) {
-    // wrench of the final x (exact: rebuilt at the last stopping test), then X_i = s_i + Gam_t b
-    __syncthreads();
-    if (valid && hf == 0) sm.u.itv.bwT[c][j] = bwl;
-    __syncthreads();
-    if (valid) {
+    // the wrench of the final x is still in bwT (exact: every way out of the loop rebuilds it at its last
+    // stopping test, and no factorisation -- which shares that LDS region -- follows); X_i = s_i + Gam_t b
+    if (real) {
       float* so = states + ((size_t)inst * H + j) * 13;
       const int i = j;
       if (c < 3) {
