@@ -594,8 +594,9 @@ solve_kernel(const DevParams P, const int B,
     __syncthreads();
     // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so that
     // none of it is hoisted out of the iteration loop (= holds registers during the iterations)
-    int co = c;
+    int co = c, jo = j;
     BMPC_OPAQUE(co);
+    BMPC_OPAQUE(jo);
     double mkd[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) mkd[k] = (co == k) ? 1.0 : 0.0;
@@ -790,14 +791,16 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
     for (int q = 0; q < HN; ++q) {
       const int jj = q / 6, b = q % 6;
+      // (through the opaque component index: the Gt part of the row is loop invariant, and the compiler would
+      // otherwise keep a ready-made copy of it in HN registers across the iterations)
       float v;
-      if (c < 3) v = (b < 3) ? Grow[(b < 3 ? b : 0) * HH + jj] : 0.f;
+      if (co < 3) v = (b < 3) ? Grow[(b < 3 ? b : 0) * HH + jj] : 0.f;
       else v = (b < 3) ? 0.f : Grow[(b < 3 ? 0 : b - 3) * HH + jj];   // zero unless b == c
       VROW(q) = v;
     }
 #pragma unroll
     for (int jj = 0; jj < HH; ++jj) {
-      const float mj = (jb + jj == j) ? 1.f : 0.f;
+      const float mj = (jb + jj == jo) ? 1.f : 0.f;
 #pragma unroll
       for (int b = 0; b < 6; ++b) VROW(6 * jj + b) = fmaf(mj, fv[b], VROW(6 * jj + b));
     }
@@ -824,34 +827,57 @@ solve_kernel(const DevParams P, const int B,
     // row_k / p: exact up to rounding because p <= 1 after the scaling; no second multiply, and the row is
     // never rebuilt from the column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
     constexpr int U = 6;
-    static_assert(NW % U == 0 && U % 2 == 0 && U <= HN, "sweep group must divide 6H and be even");
+    static_assert(NW % U == 0 && U % 2 == 0 && U + 1 <= HN, "sweep group must divide 6H and be even");
+    // Software pipeline: the entry of the NEXT pivot column is updated first and published at once (into the
+    // other buffer), so that its LDS round trip and the barrier overlap with the rest of this pivot's updates.
+    int pos = row;                              // rotated index of the own row (group 0)
+    int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
+    sm.piv[0][ws] = VROW(0);
 #pragma unroll 1
     for (int k0 = 0; k0 < NW; k0 += U) {
-      int pos = row - k0;                       // rotated index of the own row
-      pos += (pos < 0) ? NW : 0;
       const int ps = slot<H>(pos);
-      const int ws = hf == 0 ? ps : Dims<H>::VL + row;
+      int posn = pos - U;                       // ... and in the next group
+      posn += (posn < 0) ? NW : 0;
+      const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        float* buf = sm.piv[u & 1];
-        buf[ws] = VROW(u);
+        const float* buf = sm.piv[u & 1];
+        float* nbuf = sm.piv[(u + 1) & 1];
+        const int un = u + 1;                   // register of the next pivot column (u + 1 == U: first of the next group)
         __syncthreads();
+        const float pv = buf[u];
         const float ci = buf[ps];
-        const float pinv = rcp_approx(buf[u]);
+        const float pinv = rcp_approx(pv);
         const bool isp = (row == k0 + u);
         const float t = isp ? 1.f - pinv : ci * pinv;
         const f2 t2 = {-t, -t};
+        // the pivot row is fetched in chunks of at most CH entries (long rows: registers), the chunk with the
+        // next pivot column first
+        constexpr int CH = HN <= 32 ? HN : 32;
+        static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
 #pragma unroll
-        for (int q = 0; q < HN; q += 4) {
-          if (q + 4 <= HN) {
-            const float4 p4 = *reinterpret_cast<const float4*>(&buf[hf * HNP + q]);
-            Vr[q / 2] = __builtin_elementwise_fma(t2, f2{p4.x, p4.y}, Vr[q / 2]);
-            Vr[q / 2 + 1] = __builtin_elementwise_fma(t2, f2{p4.z, p4.w}, Vr[q / 2 + 1]);
-          } else {
-            const float2 p2 = *reinterpret_cast<const float2*>(&buf[hf * HNP + q]);
-            Vr[q / 2] = __builtin_elementwise_fma(t2, f2{p2.x, p2.y}, Vr[q / 2]);
+        for (int c0 = 0; c0 < HN; c0 += CH) {
+          const int c1 = c0 + CH < HN ? c0 + CH : HN;
+          f2 pb[CH / 2];
+#pragma unroll
+          for (int q = c0; q < c1; q += 4) {
+            if (q + 4 <= c1) {
+              const float4 p4 = *reinterpret_cast<const float4*>(&buf[hf * HNP + q]);
+              pb[(q - c0) / 2] = f2{p4.x, p4.y};
+              pb[(q - c0) / 2 + 1] = f2{p4.z, p4.w};
+            } else {
+              const float2 p2 = *reinterpret_cast<const float2*>(&buf[hf * HNP + q]);
+              pb[(q - c0) / 2] = f2{p2.x, p2.y};
+            }
           }
-          if (HN > 32 && q % 16 == 12) BMPC_FENCE();   // long rows: the pivot row is fetched in chunks of 16
+          if (c0 == 0) {
+            Vr[un >> 1] = __builtin_elementwise_fma(t2, pb[un >> 1], Vr[un >> 1]);
+            nbuf[u + 1 < U ? ws : wsn] = VROW(un);  // (after the very last pivot: a column nobody reads)
+          }
+#pragma unroll
+          for (int r = c0 / 2; r < c1 / 2; ++r)
+            if (r != (un >> 1)) Vr[r] = __builtin_elementwise_fma(t2, pb[r - c0 / 2], Vr[r]);
+          if (c1 < HN) BMPC_FENCE();
         }
         if (hf == 0) VROW(u) = isp ? -pinv : t;
       }
@@ -864,6 +890,8 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
       }
+      pos = posn;
+      ws = wsn;
     }
     if (dbg.prof) t_sweep += clock64() - t_mark;
   };
@@ -936,9 +964,9 @@ solve_kernel(const DevParams P, const int B,
       RT g0 = 0, g1 = 0, g2 = 0;
 #pragma unroll
       for (int jj = 0; jj < HH; ++jj) {
-        g0 += (RT)Grow[jj] * bsrc[jb + jj];
-        g1 += (RT)Grow[HH + jj] * bsrc[H + jb + jj];
-        g2 += (RT)Grow[2 * HH + jj] * bsrc[2 * H + jb + jj];
+        g0 += widen(Grow[jj]) * bsrc[jb + jj];
+        g1 += widen(Grow[HH + jj]) * bsrc[H + jb + jj];
+        g2 += widen(Grow[2 * HH + jj]) * bsrc[2 * H + jb + jj];
       }
       gpart = g0 + (g1 + g2);
     }
