@@ -52,6 +52,15 @@ __device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_upda
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 __device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
+#ifndef BMPC_EMU
+typedef float f16v __attribute__((ext_vector_type(16)));
+// D = A (32 x 2) B (2 x 32) + C on the matrix core.  Lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32] and
+// holds, of the 32 x 32 tile, column l % 32 and the 16 rows 8 (v / 4) + 4 (l / 32) + v % 4, v = 0..15.
+__device__ __forceinline__ void mfma_32x32x2(float a, float b, f16v& c) { c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+#endif
+#ifndef BMPC_SWEEP_MFMA
+#define BMPC_SWEEP_MFMA 1
+#endif
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
 __device__ __forceinline__ double pair_swap(double v) {
   const int lo = pair_swap_i(__double2loint(v)), hi = pair_swap_i(__double2hiint(v));
@@ -134,7 +143,7 @@ struct alignas(16) Smem {
   RT xs[H][2][6];            // x (relaxed iterate) for the exact rebuilds and the state roll-out
   // sweep pivot column, double buffered, two-half layout; behind it one dump slot per row: the half-1 lanes,
   // which hold no pivot-column entry, store there instead of branching around the store
-  alignas(16) float piv[2][Dims<H>::VL + Dims<H>::NW];
+  alignas(16) float piv[2][(Dims<H>::VL + Dims<H>::NW) > 64 * Dims<H>::NWV ? (Dims<H>::VL + Dims<H>::NW) : 64 * Dims<H>::NWV];
   alignas(16) float dsc[Dims<H>::VL];      // Jacobi scaling of the current factorisation
   // block-diagonal part of K^-1.  Foot-major: a lane's row sits at 48 B x row + const.
   // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
@@ -819,6 +828,106 @@ solve_kernel(const DevParams P, const int B,
         }
       }
     }
+#if BMPC_SWEEP_MFMA
+    // Symmetric sweep on the matrix cores, two pivots per step.  The scaled matrix (padded with an identity to
+    // NP = 32 x waves) goes through LDS from the row-half layout into 32 x 32 accumulator tiles, wave w owning
+    // tile row w.  Step (k, k + 1), S = {k, k + 1}, P = V[S, S]: the owner of the two pivot ROWS publishes them
+    // (one register each per tile: by symmetry they are also the pivot columns), every lane builds its
+    // operands from four published values and ONE v_mfma_f32_32x32x2_f32 per tile performs
+    //    V <- V - T V[S, :],   T[r, :] = V[r, S] P^-1 (r not in S),  T[r, :] = e_r - P^-1[r, :] (r in S),
+    // where the columns S of the B operand carry P - I instead of P, which leaves T itself in the columns S
+    // (= V[r, S] P^-1, the swept pivot columns) and 2 I - P^-1 in the pivot block: minus 2 on its diagonal
+    // gives -P^-1.  (All of it exact up to rounding because the scaled pivots are <= 1.)  Against the vector
+    // sweep: no broadcast fetch of whole pivot rows from LDS (8 ds_read_b128 per lane and pivot), no 15 packed
+    // FMAs per lane and pivot on the vector pipe, half the barriers.
+    {
+      constexpr int NWV = Dims<H>::NWV;
+      constexpr int NP = 32 * NWV;
+      static_assert(NP >= NW && sizeof(sm.u.fac) >= 32 * NP * sizeof(float), "staging buffer: one tile row");
+      const int w = l >> 6, n = l & 31, g = (l >> 5) & 1;
+      float* S = reinterpret_cast<float*>(&sm.u.fac);      // (the block algebra is done with this region)
+      f16v acc[NWV];
+#pragma unroll 1
+      for (int wc = 0; wc < NWV; ++wc) {                    // row halves -> tiles, one tile row at a time
+        __syncthreads();
+        if (row >= 32 * wc && row < 32 * wc + 32) {
+          float* dst = &S[(row - 32 * wc) * NP + hf * HN];
+#pragma unroll
+          for (int q = 0; q < HN / 2; ++q) *reinterpret_cast<float2*>(&dst[2 * q]) = float2{Vr[q].x, Vr[q].y};
+        }
+        __syncthreads();
+        if (w == wc) {
+#pragma unroll
+          for (int J = 0; J < NWV; ++J)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const int rl = 8 * (v / 4) + 4 * g + (v % 4), col = 32 * J + n, rr = 32 * wc + rl;
+              const float x = S[rl * NP + col];
+              acc[J][v] = (rr < NW && col < NW) ? x : (rr == col ? 1.f : 0.f);
+            }
+        }
+      }
+      float* rb = &sm.piv[0][0];                            // published pivot rows: [parity][k or k + 1][NP]
+#pragma unroll 1
+      for (int wp = 0; wp < NWV; ++wp) {
+#pragma unroll
+        for (int ip = 0; ip < 16; ++ip) {
+          const int k = 32 * wp + 2 * ip;
+          if (k >= NW) break;                               // (workgroup-uniform)
+          const int i0 = 2 * ip;                            // local row of pivot k in its tile row
+          const int g0 = (i0 / 4) % 2, v0 = 4 * (i0 / 8) + i0 % 4;
+          float* r0 = rb + (ip & 1) * 2 * NP;
+          float* r1 = r0 + NP;
+          if (w == wp && g == g0) {
+#pragma unroll
+            for (int J = 0; J < NWV; ++J) { r0[32 * J + n] = acc[J][v0]; r1[32 * J + n] = acc[J][v0 + 1]; }
+          }
+          __syncthreads();
+          const float p00 = r0[k], p01 = r0[k + 1], p11 = r1[k + 1];
+          const int ra = 32 * w + n;                        // the row this lane supplies the A operand for
+          const float x0 = r0[ra], x1 = r1[ra];             // V[ra][k], V[ra][k + 1]
+          const float id = rcp_approx(p00 * p11 - p01 * p01);
+          const float q00 = p11 * id, q01 = -p01 * id, q11 = p00 * id;     // P^-1
+          // A[ra][g] = -T[ra][g]
+          const float qa = g == 0 ? q00 : q01, qb = g == 0 ? q01 : q11;    // column g of P^-1
+          float t = x0 * qa + x1 * qb;
+          t = ra == k ? (g == 0 ? 1.f : 0.f) - qa : t;                     // e_0 - P^-1[0][g]
+          t = ra == k + 1 ? (g == 0 ? 0.f : 1.f) - qb : t;                 // e_1 - P^-1[1][g]
+          const float* rg = g == 0 ? r0 : r1;                              // B[g][:] = V[k + g][:]
+#pragma unroll
+          for (int J = 0; J < NWV; ++J) {
+            const int col = 32 * J + n;
+            const float bv = rg[col] - (col == k + g ? 1.f : 0.f);         // P - I in the columns S
+            mfma_32x32x2(-t, bv, acc[J]);
+          }
+          // pivot block: 2 I - P^-1  ->  -P^-1
+#pragma unroll
+          for (int J = 0; J < NWV; ++J) {
+            const bool own = (w == wp) && (J == wp) && (g == g0);
+            acc[J][v0] -= (own && n == i0) ? 2.f : 0.f;
+            acc[J][v0 + 1] -= (own && n == i0 + 1) ? 2.f : 0.f;
+          }
+        }
+      }
+#pragma unroll 1
+      for (int wc = 0; wc < NWV; ++wc) {                    // tiles -> row halves
+        __syncthreads();
+        if (w == wc) {
+#pragma unroll
+          for (int J = 0; J < NWV; ++J)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) S[(8 * (v / 4) + 4 * g + (v % 4)) * NP + 32 * J + n] = acc[J][v];
+        }
+        __syncthreads();
+        if (row >= 32 * wc && row < 32 * wc + 32) {
+          const float* src = &S[(row - 32 * wc) * NP + hf * HN];
+#pragma unroll
+          for (int q = 0; q < HN / 2; ++q) { const float2 x = *reinterpret_cast<const float2*>(&src[2 * q]); Vr[q] = f2{x.x, x.y}; }
+        }
+      }
+      __syncthreads();                        // the iteration's exchange vectors share this LDS region
+    }
+#else
     // Symmetric sweep with a rotating register file: at group k0 register i of half hf holds column
     // (k0 + hf HN + i) mod NW, so the pivot column is always a static register of the half-0 lanes.  Per pivot:
     // the half-0 lanes publish their entry of the pivot column (= pivot row, by symmetry), every lane fetches
@@ -893,6 +1002,7 @@ solve_kernel(const DevParams P, const int B,
       pos = posn;
       ws = wsn;
     }
+#endif
     if (dbg.prof) t_sweep += clock64() - t_mark;
   };
 
@@ -978,6 +1088,11 @@ solve_kernel(const DevParams P, const int B,
   for (it = 0; it < P.max_iter;) {
     if (need_factor) {                         // workgroup-uniform
       factor();
+#ifdef BMPC_DUMP_V
+      if (dbg.Gt && nfac == 0 && real) {       // debugging aid (emulation): -S V S of the first factorisation
+        for (int q = 0; q < HN; ++q) dbg.Gt[((size_t)inst * NW + row) * NW + hf * HN + q] = (double)VROW(q);
+      }
+#endif
       ++nfac;
       need_factor = false;
     }
