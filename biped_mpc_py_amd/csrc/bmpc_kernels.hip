@@ -52,15 +52,6 @@ __device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_upda
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 __device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
-#ifndef BMPC_EMU
-typedef float f16v __attribute__((ext_vector_type(16)));
-// D = A (32 x 2) B (2 x 32) + C on the matrix core.  Lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32] and
-// holds, of the 32 x 32 tile, column l % 32 and the 16 rows 8 (v / 4) + 4 (l / 32) + v % 4, v = 0..15.
-__device__ __forceinline__ void mfma_32x32x2(float a, float b, f16v& c) { c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-#endif
-#ifndef BMPC_SWEEP_MFMA
-#define BMPC_SWEEP_MFMA 1
-#endif
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
 __device__ __forceinline__ double pair_swap(double v) {
   const int lo = pair_swap_i(__double2loint(v)), hi = pair_swap_i(__double2hiint(v));
@@ -99,6 +90,7 @@ struct Dims {
   // the two addresses of a wave's ds_read_b128 (even lanes: half 0, odd lanes: half 1) never share a bank.
   static constexpr int HNP = ((HN + 3) / 4) * 4;
   static constexpr int VL = 2 * HNP;
+  static constexpr int PVS = ((VL + NW + 3) / 4) * 4;    // one published pivot column: two-half vector + one dump slot per row
   static_assert(HNP % 64 >= 4 && HNP % 64 <= 60, "halves of a two-half vector would collide on LDS banks");
   // Gt row half: 3 component groups x HH steps, padded to whole float4s
   static constexpr int GH = ((3 * HH + 3) / 4) * 4;
@@ -141,9 +133,9 @@ struct alignas(16) Smem {
     IterScratch<H> itv;
   } u;
   RT xs[H][2][6];            // x (relaxed iterate) for the exact rebuilds and the state roll-out
-  // sweep pivot column, double buffered, two-half layout; behind it one dump slot per row: the half-1 lanes,
-  // which hold no pivot-column entry, store there instead of branching around the store
-  alignas(16) float piv[2][(Dims<H>::VL + Dims<H>::NW) > 64 * Dims<H>::NWV ? (Dims<H>::VL + Dims<H>::NW) : 64 * Dims<H>::NWV];
+  // the two pivot columns of a sweep step, double buffered, two-half layout; behind each one dump slot per row:
+  // the half-1 lanes, which hold no pivot-column entry, store there instead of branching around the store
+  alignas(16) float piv[2][2 * Dims<H>::PVS];
   alignas(16) float dsc[Dims<H>::VL];      // Jacobi scaling of the current factorisation
   // block-diagonal part of K^-1.  Foot-major: a lane's row sits at 48 B x row + const.
   // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
@@ -217,7 +209,6 @@ __device__ __forceinline__ void row_times_mat6(const double (&w)[6], const doubl
     }
 #pragma unroll
     for (int b = 0; b < 6; ++b) out[b] = fma(w[q], row[b], out[b]);
-    if (q & 1) BMPC_FENCE();            // at most two rows in flight: the scheduler otherwise hoists all 36 doubles
   }
 }
 
@@ -828,120 +819,26 @@ solve_kernel(const DevParams P, const int B,
         }
       }
     }
-#if BMPC_SWEEP_MFMA
-    // Symmetric sweep on the matrix cores, two pivots per step.  The scaled matrix (padded with an identity to
-    // NP = 32 x waves) goes through LDS from the row-half layout into 32 x 32 accumulator tiles, wave w owning
-    // tile row w.  Step (k, k + 1), S = {k, k + 1}, P = V[S, S]: the owner of the two pivot ROWS publishes them
-    // (one register each per tile: by symmetry they are also the pivot columns), every lane builds its
-    // operands from four published values and ONE v_mfma_f32_32x32x2_f32 per tile performs
-    //    V <- V - T V[S, :],   T[r, :] = V[r, S] P^-1 (r not in S),  T[r, :] = e_r - P^-1[r, :] (r in S),
-    // where the columns S of the B operand carry P - I instead of P, which leaves T itself in the columns S
-    // (= V[r, S] P^-1, the swept pivot columns) and 2 I - P^-1 in the pivot block: minus 2 on its diagonal
-    // gives -P^-1.  (All of it exact up to rounding because the scaled pivots are <= 1.)  Against the vector
-    // sweep: no broadcast fetch of whole pivot rows from LDS (8 ds_read_b128 per lane and pivot), no 15 packed
-    // FMAs per lane and pivot on the vector pipe, half the barriers.
-    {
-      constexpr int NWV = Dims<H>::NWV;
-      constexpr int NP = 32 * NWV;
-      static_assert(NP >= NW && sizeof(sm.u.fac) >= 32 * NP * sizeof(float), "staging buffer: one tile row");
-      const int w = l >> 6, n = l & 31, g = (l >> 5) & 1;
-      float* S = reinterpret_cast<float*>(&sm.u.fac);      // (the block algebra is done with this region)
-      f16v acc[NWV];
-#pragma unroll 1
-      for (int wc = 0; wc < NWV; ++wc) {                    // row halves -> tiles, one tile row at a time
-        __syncthreads();
-        if (row >= 32 * wc && row < 32 * wc + 32) {
-          float* dst = &S[(row - 32 * wc) * NP + hf * HN];
-#pragma unroll
-          for (int q = 0; q < HN / 2; ++q) *reinterpret_cast<float2*>(&dst[2 * q]) = float2{Vr[q].x, Vr[q].y};
-        }
-        __syncthreads();
-        if (w == wc) {
-#pragma unroll
-          for (int J = 0; J < NWV; ++J)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-              const int rl = 8 * (v / 4) + 4 * g + (v % 4), col = 32 * J + n, rr = 32 * wc + rl;
-              const float x = S[rl * NP + col];
-              acc[J][v] = (rr < NW && col < NW) ? x : (rr == col ? 1.f : 0.f);
-            }
-        }
-      }
-      float* rb = &sm.piv[0][0];                            // published pivot rows: [parity][k or k + 1][NP]
-#pragma unroll 1
-      for (int wp = 0; wp < NWV; ++wp) {
-#pragma unroll
-        for (int ip = 0; ip < 16; ++ip) {
-          const int k = 32 * wp + 2 * ip;
-          if (k >= NW) break;                               // (workgroup-uniform)
-          const int i0 = 2 * ip;                            // local row of pivot k in its tile row
-          const int g0 = (i0 / 4) % 2, v0 = 4 * (i0 / 8) + i0 % 4;
-          float* r0 = rb + (ip & 1) * 2 * NP;
-          float* r1 = r0 + NP;
-          if (w == wp && g == g0) {
-#pragma unroll
-            for (int J = 0; J < NWV; ++J) { r0[32 * J + n] = acc[J][v0]; r1[32 * J + n] = acc[J][v0 + 1]; }
-          }
-          __syncthreads();
-          const float p00 = r0[k], p01 = r0[k + 1], p11 = r1[k + 1];
-          const int ra = 32 * w + n;                        // the row this lane supplies the A operand for
-          const float x0 = r0[ra], x1 = r1[ra];             // V[ra][k], V[ra][k + 1]
-          const float id = rcp_approx(p00 * p11 - p01 * p01);
-          const float q00 = p11 * id, q01 = -p01 * id, q11 = p00 * id;     // P^-1
-          // A[ra][g] = -T[ra][g]
-          const float qa = g == 0 ? q00 : q01, qb = g == 0 ? q01 : q11;    // column g of P^-1
-          float t = x0 * qa + x1 * qb;
-          t = ra == k ? (g == 0 ? 1.f : 0.f) - qa : t;                     // e_0 - P^-1[0][g]
-          t = ra == k + 1 ? (g == 0 ? 0.f : 1.f) - qb : t;                 // e_1 - P^-1[1][g]
-          const float* rg = g == 0 ? r0 : r1;                              // B[g][:] = V[k + g][:]
-#pragma unroll
-          for (int J = 0; J < NWV; ++J) {
-            const int col = 32 * J + n;
-            const float bv = rg[col] - (col == k + g ? 1.f : 0.f);         // P - I in the columns S
-            mfma_32x32x2(-t, bv, acc[J]);
-          }
-          // pivot block: 2 I - P^-1  ->  -P^-1
-#pragma unroll
-          for (int J = 0; J < NWV; ++J) {
-            const bool own = (w == wp) && (J == wp) && (g == g0);
-            acc[J][v0] -= (own && n == i0) ? 2.f : 0.f;
-            acc[J][v0 + 1] -= (own && n == i0 + 1) ? 2.f : 0.f;
-          }
-        }
-      }
-#pragma unroll 1
-      for (int wc = 0; wc < NWV; ++wc) {                    // tiles -> row halves
-        __syncthreads();
-        if (w == wc) {
-#pragma unroll
-          for (int J = 0; J < NWV; ++J)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) S[(8 * (v / 4) + 4 * g + (v % 4)) * NP + 32 * J + n] = acc[J][v];
-        }
-        __syncthreads();
-        if (row >= 32 * wc && row < 32 * wc + 32) {
-          const float* src = &S[(row - 32 * wc) * NP + hf * HN];
-#pragma unroll
-          for (int q = 0; q < HN / 2; ++q) { const float2 x = *reinterpret_cast<const float2*>(&src[2 * q]); Vr[q] = f2{x.x, x.y}; }
-        }
-      }
-      __syncthreads();                        // the iteration's exchange vectors share this LDS region
-    }
-#else
-    // Symmetric sweep with a rotating register file: at group k0 register i of half hf holds column
-    // (k0 + hf HN + i) mod NW, so the pivot column is always a static register of the half-0 lanes.  Per pivot:
-    // the half-0 lanes publish their entry of the pivot column (= pivot row, by symmetry), every lane fetches
-    // the HN entries of its half and updates with ONE packed FMA per pair: row -= t * pivot row, with
-    // t = a_ik / p for the other rows and t = 1 - 1/p for the pivot row itself (row_k - (1 - 1/p) row_k =
-    // row_k / p: exact up to rounding because p <= 1 after the scaling; no second multiply, and the row is
-    // never rebuilt from the column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
+    // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of half hf
+    // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always one static register pair
+    // of the half-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the half-0 lanes publish their two entries of the
+    // pivot columns (= pivot rows, by symmetry), every lane fetches the 2 HN entries of its half, forms its
+    // T[r, :] = V[r, S] P^-1 and updates with TWO packed FMAs per register pair:  row -= T[r, 0] row_k +
+    // T[r, 1] row_k+1; the pivot rows themselves use T[r, :] = e_r - P^-1[r, :], which turns them into
+    // P^-1 V[S, :] (exact up to rounding because the scaled pivots are <= 1; no second multiply, and a row is
+    // never rebuilt from a column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
+    // The entries in the columns S become T (V[r, S] P^-1) and, in the pivot block, -P^-1.
+    // Two pivots per barrier and LDS round trip instead of one; the update of the NEXT pair of pivot columns
+    // is done first and published at once (into the other buffer), so that its round trip overlaps with the
+    // rest of this step's updates.
     constexpr int U = 6;
-    static_assert(NW % U == 0 && U % 2 == 0 && U + 1 <= HN, "sweep group must divide 6H and be even");
-    // Software pipeline: the entry of the NEXT pivot column is updated first and published at once (into the
-    // other buffer), so that its LDS round trip and the barrier overlap with the rest of this pivot's updates.
+    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
+    constexpr int PVS = Dims<H>::PVS;            // floats per published column (two-half layout + dump slots)
     int pos = row;                              // rotated index of the own row (group 0)
     int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
-    sm.piv[0][ws] = VROW(0);
+    sm.piv[0][ws] = Vr[0].x;
+    sm.piv[0][PVS + ws] = Vr[0].y;
+    int par = 0;                                // buffer of the current step (a group has an odd number of steps)
 #pragma unroll 1
     for (int k0 = 0; k0 < NW; k0 += U) {
       const int ps = slot<H>(pos);
@@ -949,46 +846,58 @@ solve_kernel(const DevParams P, const int B,
       posn += (posn < 0) ? NW : 0;
       const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float* buf = sm.piv[u & 1];
-        float* nbuf = sm.piv[(u + 1) & 1];
-        const int un = u + 1;                   // register of the next pivot column (u + 1 == U: first of the next group)
+      for (int u = 0; u < U; u += 2) {
+        const float* bA = sm.piv[par];                   // column k
+        const float* bB = bA + PVS;                      // column k + 1
+        float* nA = sm.piv[par ^ 1];
+        par ^= 1;
+        const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
         __syncthreads();
-        const float pv = buf[u];
-        const float ci = buf[ps];
-        const float pinv = rcp_approx(pv);
-        const bool isp = (row == k0 + u);
-        const float t = isp ? 1.f - pinv : ci * pinv;
-        const f2 t2 = {-t, -t};
-        // the pivot row is fetched in chunks of at most CH entries (long rows: registers), the chunk with the
-        // next pivot column first
-        constexpr int CH = HN <= 32 ? HN : 32;
+        const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
+        const float p11 = bB[u + 1];
+        const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
+        const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
+        const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
+        const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
+        float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
+        t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
+        t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
+        const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
+        // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the
+        // next pivot columns first
+        constexpr int CH = HN <= 32 ? HN : 16;
         static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
 #pragma unroll
-        for (int c0 = 0; c0 < HN; c0 += CH) {
-          const int c1 = c0 + CH < HN ? c0 + CH : HN;
-          f2 pb[CH / 2];
+        for (int c0i = 0; c0i < HN; c0i += CH) {
+          const int c1i = c0i + CH < HN ? c0i + CH : HN;
+          f2 pa[CH / 2], pb[CH / 2];
 #pragma unroll
-          for (int q = c0; q < c1; q += 4) {
-            if (q + 4 <= c1) {
-              const float4 p4 = *reinterpret_cast<const float4*>(&buf[hf * HNP + q]);
-              pb[(q - c0) / 2] = f2{p4.x, p4.y};
-              pb[(q - c0) / 2 + 1] = f2{p4.z, p4.w};
+          for (int q = c0i; q < c1i; q += 4) {
+            if (q + 4 <= c1i) {
+              const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
+              const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
+              pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
             } else {
-              const float2 p2 = *reinterpret_cast<const float2*>(&buf[hf * HNP + q]);
-              pb[(q - c0) / 2] = f2{p2.x, p2.y};
+              const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
+              const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a2.x, a2.y};
+              pb[(q - c0i) / 2] = f2{b2.x, b2.y};
             }
           }
-          if (c0 == 0) {
-            Vr[un >> 1] = __builtin_elementwise_fma(t2, pb[un >> 1], Vr[un >> 1]);
-            nbuf[u + 1 < U ? ws : wsn] = VROW(un);  // (after the very last pivot: a column nobody reads)
+          if (c0i == 0) {
+            static_assert(U / 2 + 1 <= CH / 2, "the next pivot pair lies in the first chunk");
+            Vr[un] = __builtin_elementwise_fma(m1, pb[un], __builtin_elementwise_fma(m0, pa[un], Vr[un]));
+            const int wn = u + 2 < U ? ws : wsn;         // (after the very last step: columns nobody reads)
+            nA[wn] = Vr[un].x;
+            nA[PVS + wn] = Vr[un].y;
           }
 #pragma unroll
-          for (int r = c0 / 2; r < c1 / 2; ++r)
-            if (r != (un >> 1)) Vr[r] = __builtin_elementwise_fma(t2, pb[r - c0 / 2], Vr[r]);
-          if (c1 < HN) BMPC_FENCE();
+          for (int r = c0i / 2; r < c1i / 2; ++r)
+            if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
+          if (c1i < HN) BMPC_FENCE();
         }
-        if (hf == 0) VROW(u) = isp ? -pinv : t;
+        if (hf == 0) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
       }
       {                                        // rotate left by U across the pair
         f2 tmp[U / 2];
@@ -1002,7 +911,6 @@ solve_kernel(const DevParams P, const int B,
       pos = posn;
       ws = wsn;
     }
-#endif
     if (dbg.prof) t_sweep += clock64() - t_mark;
   };
 
@@ -1088,11 +996,6 @@ solve_kernel(const DevParams P, const int B,
   for (it = 0; it < P.max_iter;) {
     if (need_factor) {                         // workgroup-uniform
       factor();
-#ifdef BMPC_DUMP_V
-      if (dbg.Gt && nfac == 0 && real) {       // debugging aid (emulation): -S V S of the first factorisation
-        for (int q = 0; q < HN; ++q) dbg.Gt[((size_t)inst * NW + row) * NW + hf * HN + q] = (double)VROW(q);
-      }
-#endif
       ++nfac;
       need_factor = false;
     }

@@ -72,22 +72,6 @@ static inline int pair_swap_i(int v) {
   __syncthreads();
   return r;
 }
-typedef float f16v __attribute__((ext_vector_type(16)));
-static float g_ma[1024], g_mb[1024];
-// v_mfma_f32_32x32x2_f32 of the lane's wave: D = A B + C, operand and accumulator layout as on the device
-static inline void mfma_32x32x2(float a, float b, f16v& c) {
-  g_ma[threadIdx.x] = a;
-  g_mb[threadIdx.x] = b;
-  __syncthreads();
-  const int w0 = threadIdx.x & ~63, lw = threadIdx.x & 63, n = lw & 31, g = lw >> 5;
-  for (int v = 0; v < 16; ++v) {
-    const int i = 8 * (v / 4) + 4 * g + (v % 4);
-    float acc = c[v];
-    for (int kk = 0; kk < 2; ++kk) acc = std::fma(g_ma[w0 + 32 * kk + i], g_mb[w0 + 32 * kk + n], acc);
-    c[v] = acc;
-  }
-  __syncthreads();
-}
 static inline unsigned wave_umax(unsigned v) {          // maximum over the lane's wave (64 consecutive lanes)
   g_red[threadIdx.x] = v;
   __syncthreads();
