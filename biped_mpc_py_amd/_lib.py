@@ -19,6 +19,7 @@ EXPORTS = (
     "bmpc_foot_position_world", "bmpc_foot_position_world_device",
     "bmpc_low_level_control", "bmpc_low_level_control_device",
     "bmpc_gait_default", "bmpc_contact_sequence", "bmpc_contact_sequence_device",
+    "bmpc_set_warm_start", "bmpc_reset_warm_start", "bmpc_rollout_device",
 )
 
 
@@ -109,6 +110,9 @@ def load():
     lib.bmpc_gait_default.argtypes = [C.POINTER(CGait), ip]
     lib.bmpc_contact_sequence.argtypes = [vp, ip, vp, C.POINTER(CGait), vp, vp]
     lib.bmpc_contact_sequence_device.argtypes = [vp, ip, vp, C.POINTER(CGait), vp, vp, vp]
+    lib.bmpc_set_warm_start.argtypes = [vp, ip, ip, C.c_double]
+    lib.bmpc_reset_warm_start.argtypes = [vp]
+    lib.bmpc_rollout_device.argtypes = [vp, ip, ip, vp, vp, vp, C.POINTER(CGait), vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "bmpc_last_error":

@@ -231,6 +231,55 @@ class BatchSolver:
                                                           phase.data_ptr(), contact.data_ptr(), st))
         return phase, contact
 
+    # ---- receding-horizon use --------------------------------------------------
+    def set_warm_start(self, enable=True, shift=0, theta=0.5):
+        """Later solves of the same batch size start from the state the previous solve left on the device
+        (`bmpc_set_warm_start`): `shift` horizon steps later, penalties pulled back by rho0 (rho / rho0)^theta."""
+        _lib.check(self._lib.bmpc_set_warm_start(self._h, 1 if enable else 0, int(shift), float(theta)))
+
+    def reset_warm_start(self):
+        _lib.check(self._lib.bmpc_reset_warm_start(self._h))
+
+    def rollout_device(self, x_fb, foot, t, steps, x_cmd=None, mu=None, period=None, offset=None, duty=None,
+                       want_iters=True, stream=None):
+        """`steps` closed-loop control periods on device tensors (`bmpc_rollout_device`): x_fb (B,12) float32 and
+        t (B,) float64 are advanced IN PLACE; returns dict(u0 (steps,B,12), x (steps,B,12), iters (steps,B) | None,
+        status_any (B,)).  Asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        dev = x_fb.device
+        B = x_fb.shape[0]
+        if dev.type != "cuda" or dev.index != self.device:
+            raise ValueError(f"tensors must live on cuda:{self.device}")
+
+        def chk(tn, dtype, shape):
+            if tn is None:
+                return None
+            if tn.device != dev or tn.dtype != dtype or not tn.is_contiguous() or tuple(tn.shape) != shape:
+                raise ValueError(f"expected contiguous {dtype} tensor of shape {shape} on {dev}")
+            return tn.data_ptr()
+
+        gait = None
+        if period is not None or offset is not None or duty is not None:
+            gait = _lib.CGait()
+            _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
+            if period is not None:
+                gait.period = int(period)
+            if offset is not None:
+                gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
+            if duty is not None:
+                gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        u0 = torch.empty((steps, B, 12), dtype=torch.float32, device=dev)
+        xt = torch.empty((steps, B, 12), dtype=torch.float32, device=dev)
+        its = torch.empty((steps, B), dtype=torch.int32, device=dev) if want_iters else None
+        st_any = torch.empty(B, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(self._lib.bmpc_rollout_device(
+            self._h, B, int(steps), chk(x_fb, torch.float32, (B, 12)), chk(foot, torch.float32, (B, 6)),
+            chk(t, torch.float64, (B,)), None if gait is None else C.byref(gait), chk(x_cmd, torch.float32, (B, 12)),
+            chk(mu, torch.float32, (B, self.h, 2)), u0.data_ptr(), xt.data_ptr(), None if its is None else its.data_ptr(),
+            st_any.data_ptr(), st))
+        return dict(u0=u0, x=xt, iters=its, status_any=st_any)
+
     def last_kernel_ms(self):
         ms = C.c_float(-1.0)
         _lib.check(self._lib.bmpc_last_kernel_ms(self._h, C.byref(ms)))

@@ -108,6 +108,15 @@ struct bmpc_handle_s {
   DevBuf<double> ll_t;
   DevBuf<uint8_t> ll_c0;
   long long* prof_dev = nullptr;   // optional cycle-stamp buffer (bmpc_debug_set_profile)
+  // receding-horizon warm start (bmpc_set_warm_start): solver state of the last batch, kept on the device
+  DevBuf<double> warm;
+  bool warm_on = false, warm_valid = false;
+  int warm_batch = 0, warm_shift = 0;
+  float warm_theta = 0.5f;
+  // roll-out scratch (bmpc_rollout_device)
+  DevBuf<float> ro_controls, ro_states;
+  DevBuf<uint8_t> ro_contact;
+  DevBuf<int32_t> ro_phase, ro_iters, ro_status;
 };
 
 namespace {
@@ -118,9 +127,21 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
              hipStream_t st) {
   constexpr int NT = bmpc::Dims<H>::NT;
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f};
+  if (hd->warm_on && !dbg.assemble_only) {
+    const size_t need = (size_t)B * NT * 6;
+    if (need > hd->warm.n) hd->warm_valid = false;          // growing the buffer loses the stored state
+    HIP_TRY(hd->warm.ensure(need));
+    warm.buf = hd->warm.p;
+    warm.load = (hd->warm_valid && hd->warm_batch == B) ? 1 : 0;
+    warm.store = 1;
+    warm.shift = hd->warm_shift;
+    warm.theta = hd->warm_theta;
+  }
   hipLaunchKernelGGL((bmpc::solve_kernel<H>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
-                     phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg);
+                     phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
   HIP_TRY(hipGetLastError());
+  if (warm.buf) { hd->warm_valid = true; hd->warm_batch = B; }
   return BMPC_OK;
 }
 
@@ -223,6 +244,8 @@ int bmpc_destroy(bmpc_handle h) {
   h->status.release(); h->nfactor.release(); h->dbg.release();
   h->ll_q.release(); h->ll_qd.release(); h->ll_pf.release(); h->ll_u0.release(); h->ll_tau.release();
   h->ll_t.release(); h->ll_c0.release();
+  h->warm.release(); h->ro_controls.release(); h->ro_states.release(); h->ro_contact.release();
+  h->ro_phase.release(); h->ro_iters.release(); h->ro_status.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -473,6 +496,54 @@ int bmpc_contact_sequence(bmpc_handle h, int B, const double* t, const bmpc_gait
   if (phase) HIP_TRY(hipMemcpyAsync(phase, h->phase.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   if (contact) HIP_TRY(hipMemcpyAsync(contact, h->contact.p, n * hh * 2, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return BMPC_OK;
+}
+
+int bmpc_set_warm_start(bmpc_handle h, int enable, int shift, double theta) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (shift < 0 || shift >= h->params.h) return fail(BMPC_ERR_INVALID, "shift must be in [0, h)");
+  if (!(theta >= 0.0 && theta <= 1.0)) return fail(BMPC_ERR_INVALID, "theta must be in [0, 1]");
+  h->warm_on = enable != 0;
+  h->warm_shift = shift;
+  h->warm_theta = (float)theta;
+  if (!h->warm_on) h->warm_valid = false;
+  return BMPC_OK;
+}
+
+int bmpc_reset_warm_start(bmpc_handle h) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  h->warm_valid = false;
+  return BMPC_OK;
+}
+
+int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const float* foot, double* t,
+                        const bmpc_gait* gait, const float* x_cmd, const float* mu, float* u0_traj, float* x_traj,
+                        int32_t* iters_traj, int32_t* status_any, void* stream) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  if (B < 0 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, h->max_batch);
+  if (steps < 0) return fail(BMPC_ERR_INVALID, "steps must be >= 0");
+  if (B == 0 || steps == 0) return BMPC_OK;
+  if (!x_fb || !foot || !t) return fail(BMPC_ERR_INVALID, "x_fb, foot and t must be non-null");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B, H = (size_t)h->dev.h;
+  HIP_TRY(h->ro_controls.ensure(n * H * 12)); HIP_TRY(h->ro_states.ensure(n * H * 13));
+  HIP_TRY(h->ro_contact.ensure(n * H * 2)); HIP_TRY(h->ro_phase.ensure(n));
+  HIP_TRY(h->ro_iters.ensure(n)); HIP_TRY(h->ro_status.ensure(n));
+  hipStream_t st = pick_stream(h, stream);
+  if (status_any) HIP_TRY(hipMemsetAsync(status_any, 0, n * sizeof(int32_t), st));
+  for (int s = 0; s < steps; ++s) {
+    // t -> (phase, contact) -> solve -> x_fb <- states[:, 0], t += dt: three launches on one stream, no host arithmetic
+    int rc = bmpc_contact_sequence_device(h, B, t, gait, h->ro_phase.p, h->ro_contact.p, st);
+    if (rc != BMPC_OK) return rc;
+    rc = bmpc_solve_batch_device(h, B, x_fb, foot, h->ro_contact.p, h->ro_phase.p, x_cmd, mu, h->ro_controls.p,
+                                 h->ro_states.p, h->ro_iters.p, nullptr, h->ro_status.p, nullptr, st);
+    if (rc != BMPC_OK) return rc;
+    hipLaunchKernelGGL(bmpc::rollout_feedback_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, (int)H, h->params.dt,
+                       h->ro_states.p, h->ro_controls.p, h->ro_iters.p, h->ro_status.p, x_fb, t,
+                       u0_traj ? u0_traj + (size_t)s * n * 12 : nullptr, x_traj ? x_traj + (size_t)s * n * 12 : nullptr,
+                       iters_traj ? iters_traj + (size_t)s * n : nullptr, status_any);
+    HIP_TRY(hipGetLastError());
+  }
   return BMPC_OK;
 }
 

@@ -76,6 +76,15 @@ struct DebugOut {            // all nullable, fp64, device pointers
   int assemble_only;
 };
 
+// Receding-horizon warm start: per lane the iterate (x, z, y of its box and general row)
+// and its two penalties, kept in HBM between solves of the same batch slot.
+struct WarmArgs {
+  double* buf;               // [B][NT][6] or null: {x, z_box, z_gen, y_box, y_gen, (rho_box, rho_gen) as two floats}
+  int load, store;           // start from buf / leave the final state in buf
+  int shift;                 // the stored horizon is advanced by this many steps on load (0: same schedule phase)
+  float theta;               // penalties restart at rho0 (rho_stored / rho0)^theta: 1 keeps them, 0 forgets them
+};
+
 template <int H>
 struct Dims {
   static_assert(H % 2 == 0, "the column halves are whole steps");
@@ -140,8 +149,11 @@ struct alignas(16) Smem {
   // block-diagonal part of K^-1.  Foot-major: a lane's row sits at 48 B x row + const.
   // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
   // products against (t, gamma) and run as one packed FMA per term.
-  alignas(16) float LG[2][H][6][6][2];  // {L, G L}:   L_j = D^-1 W' F            [foot][step][var][wrench comp]
-  alignas(16) float KG[2][H][6][6][2];  // {Kn, G Kn}: Kn = Ka^-1 (foot 0), T Ka^-1 (foot 1); N Ka^-1 N' r = N (Ka^-1 (N' r))
+  // The two feet's blocks start 2 (mod 4) dwords apart: a wave's 8-byte reads of the rows (12 dwords apart) then
+  // use banks 4 m, 4 m + 1 for foot 0 and 4 m + 2, 4 m + 3 for foot 1 instead of colliding pairwise.
+  struct alignas(8) FootBlock { float d[H][6][6][2]; float pad[2]; };
+  alignas(16) FootBlock LG[2];          // {L, G L}:   L_j = D^-1 W' F            [foot].d[step][var][wrench comp]
+  alignas(16) FootBlock KG[2];          // {Kn, G Kn}: Kn = Ka^-1 (foot 0), T Ka^-1 (foot 1); N Ka^-1 N' r = N (Ka^-1 (N' r))
   // step data
   RT Iw[H][9];               // world inverse inertia
   RT rr[H][2][3];            // r_f = foot_ref - com_ref
@@ -279,7 +291,7 @@ solve_kernel(const DevParams P, const int B,
              float* __restrict__ controls, float* __restrict__ states,
              int32_t* __restrict__ iters_out, float* __restrict__ resid_out,
              int32_t* __restrict__ status_out, int32_t* __restrict__ nfactor_out,
-             const DebugOut dbg) {
+             const DebugOut dbg, const WarmArgs warm) {
   constexpr int NW = Dims<H>::NW;
   constexpr int HN = Dims<H>::HN;
   constexpr int HH = Dims<H>::HH;
@@ -728,7 +740,7 @@ solve_kernel(const DevParams P, const int B,
       if (hf == 0) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          sm.LG[0][j][c][b][0] = (float)w0[b];
+          sm.LG[0].d[j][c][b][0] = (float)w0[b];
           sm.u.fac.M2[j][c][b] = w0[b];         // L_0 rows for F
         }
       } else {
@@ -741,7 +753,7 @@ solve_kernel(const DevParams P, const int B,
     if (on0) {
       row_times_mat6(urow, sm.u.fac.M2[j], fv64);     // F = U L_0
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.KG[0][j][c][b][0] = (float)ka[b];
+      for (int b = 0; b < 6; ++b) sm.KG[0].d[j][c][b][0] = (float)ka[b];
     }
     if (on1) {
       double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -749,9 +761,9 @@ solve_kernel(const DevParams P, const int B,
       row_times_mat6(Trow, sm.u.fac.M1[j], sk);       // T Ka^-1
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        sm.LG[1][j][c][b][0] = (float)sl[b];
+        sm.LG[1].d[j][c][b][0] = (float)sl[b];
         // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
-        sm.KG[1][j][c][b][0] = (float)sk[b];
+        sm.KG[1].d[j][c][b][0] = (float)sk[b];
       }
     }
     __syncthreads();
@@ -764,11 +776,11 @@ solve_kernel(const DevParams P, const int B,
         float gk = 0.f, gl = 0.f;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          gk = fmaf(gr[b], sm.KG[f][j][b][i][0], gk);
-          gl = fmaf(gr[b], sm.LG[f][j][b][i][0], gl);
+          gk = fmaf(gr[b], sm.KG[f].d[j][b][i][0], gk);
+          gl = fmaf(gr[b], sm.LG[f].d[j][b][i][0], gl);
         }
-        sm.KG[f][j][c][i][1] = gk;
-        sm.LG[f][j][c][i][1] = gl;
+        sm.KG[f].d[j][c][i][1] = gk;
+        sm.LG[f].d[j][c][i][1] = gl;
       }
     }
     if (dbg.prof) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
@@ -992,6 +1004,35 @@ solve_kernel(const DevParams P, const int B,
     gbl = gpart + sm.qtl[row];
   };
 
+  if (warm.buf && warm.load) {                 // workgroup-uniform
+    // Start from the previous solve of this batch slot: iterate and multipliers of the lane that owned the same
+    // variable `shift` steps later (the last step repeats), projected onto the new bounds; penalties pulled back
+    // towards rho0 so that a row whose activity changed needs one or two moves, not four.  A state that is not
+    // finite (a failed solve) is ignored.
+    int js = j + warm.shift;
+    js = js > H - 1 ? H - 1 : js;
+    const double* src = warm.buf + ((size_t)inst * NT + (2 * (6 * js + c) + f)) * 6;
+    double wv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wv[k] = src[k];
+    const float pb0 = __int_as_float(__double2loint(wv[5])), pg0 = __int_as_float(__double2hiint(wv[5]));
+    bool ok = pb0 > 0.f && pg0 > 0.f && pb0 < 3.0e38f && pg0 < 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ok = ok && (fabs(wv[k]) < 1.0e300);
+    if (ok) {
+      xo = wv[0];
+      zb = fmin(fmax(wv[1], (RT)lb), (RT)ub);
+      zg = fmin(wv[2], (RT)0);
+      yb = wv[3];
+      yg = wv[4];
+      const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+      rvb = eqb ? P.rho_eq : fminf(fmaxf(P.rho * powf(pb0 / P.rho, warm.theta), P.rho_lo), hib);
+      rvg = fminf(fmaxf(P.rho * powf(pg0 / P.rho, warm.theta), P.rho_lo), hig);
+      irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
+    }
+    refresh();                                 // axg, gbl of the loaded x (barriers inside: all lanes)
+  }
+
 #pragma unroll 1
   for (it = 0; it < P.max_iter;) {
     if (need_factor) {                         // workgroup-uniform
@@ -1032,7 +1073,7 @@ solve_kernel(const DevParams P, const int B,
       const RT wt = g1 * sm.rx[j][f][c][0] - g2 * sm.rx[j][f][c][1] + gsel;
       sm.u.itv.r32[j][f][c] = (float)(r + wt);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f][j][i][c][0];
+      for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f].d[j][i][c][0];
     }
     __syncthreads();
     BMPC_STAMP(2)
@@ -1095,8 +1136,8 @@ solve_kernel(const DevParams P, const int B,
       f2 kg[6], lg[6];                         // rows c of {Kn, G Kn} and {L, G L} of the own foot
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f][j][c][i][0]);
-        lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f][j][c][i][0]);
+        kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
+        lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
       }
       // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
       float tn[6];
@@ -1228,6 +1269,11 @@ solve_kernel(const DevParams P, const int B,
     BMPC_STAMP(6)
   }
   if (valid) sm.xs[j][f][c] = xo;              // for the state roll-out below
+  if (warm.buf && warm.store) {
+    double* dst = warm.buf + ((size_t)inst * NT + l) * 6;
+    dst[0] = xo; dst[1] = zb; dst[2] = zg; dst[3] = yb; dst[4] = yg;
+    dst[5] = __hiloint2double(__float_as_int(rvg), __float_as_int(rvb));
+  }
 
   // ------------------------------------------------------------------ F. outputs (REF:300-304)
   if (real) {

@@ -196,4 +196,28 @@ gait_kernel(const GaitParams G, const int B, const double* __restrict__ t, int32
   }
 }
 
+// One closed-loop step of the batched roll-out: the MPC's own prediction of the next
+// state (row 0 of `states`, REF:301) becomes the state feedback, time advances by dt, and the applied control /
+// the new state / the solver's iteration count are recorded.  One thread per instance.
+__global__ void rollout_feedback_kernel(int B, int h, double dt, const float* __restrict__ states,
+                                        const float* __restrict__ controls, const int32_t* __restrict__ iters,
+                                        const int32_t* __restrict__ status, float* __restrict__ x_fb,
+                                        double* __restrict__ t, float* __restrict__ u0_out, float* __restrict__ x_out,
+                                        int32_t* __restrict__ iters_out, int32_t* __restrict__ status_any) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* s0 = states + (size_t)b * h * 13;
+  const float* u0 = controls + (size_t)b * h * 12;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float v = s0[i];
+    x_fb[(size_t)b * 12 + i] = v;
+    if (x_out) x_out[(size_t)b * 12 + i] = v;
+    if (u0_out) u0_out[(size_t)b * 12 + i] = u0[i];
+  }
+  t[b] += dt;
+  if (iters_out) iters_out[b] = iters[b];
+  if (status_any) status_any[b] |= status[b];
+}
+
 }  // namespace bmpc

@@ -193,6 +193,32 @@ int bmpc_contact_sequence(bmpc_handle h, int B, const double* t, const bmpc_gait
 int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bmpc_gait* gait, int32_t* phase,
                                  uint8_t* contact, void* stream);
 
+/*
+ * Receding-horizon use (the reference solves one step, REF:13-17, and lists real-time use as
+ * its TODO, README.md:6-7).
+ *
+ * bmpc_set_warm_start: with enable != 0 every later bmpc_solve_batch* call through this handle leaves the final
+ * solver state of each instance (iterate, multipliers, per-row penalties: 48 B per lane) in a device buffer owned
+ * by the handle, and starts from the state the previous call left for the same batch index (same B), advanced by
+ * `shift` horizon steps (0: the schedule phase did not move; 1: one control period later) and with the penalties
+ * pulled back towards their initial value, rho0 (rho / rho0)^theta (theta in [0, 1]; 1 keeps them).  The first
+ * call after enabling, after bmpc_reset_warm_start, or with another B starts cold.  The optimum is the same; only
+ * the iteration count changes.  enable == 0 switches it off.
+ *
+ * bmpc_rollout_device: `steps` closed-loop control periods of B instances on one stream, DEVICE pointers, no host
+ * arithmetic and no synchronisation: per period  t -> (phase, contact) [bmpc_contact_sequence_device]  ->  solve
+ * [bmpc_solve_batch_device]  ->  x_fb <- states[:, 0, 0:12] (the model's own prediction, REF:301), t += dt.
+ *   x_fb [B][12] in/out, foot [B][6], t [B] fp64 in/out, gait NULL = the handle's default schedule,
+ *   x_cmd [B][12] or NULL, mu [B][h][2] or NULL (constant over the roll-out);
+ *   u0_traj [steps][B][12], x_traj [steps][B][12] (state after each period), iters_traj [steps][B],
+ *   status_any [B] (OR of the per-period status values): each may be NULL.
+ */
+int bmpc_set_warm_start(bmpc_handle h, int enable, int shift, double theta);
+int bmpc_reset_warm_start(bmpc_handle h);
+int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const float* foot, double* t,
+                        const bmpc_gait* gait, const float* x_cmd, const float* mu,
+                        float* u0_traj, float* x_traj, int32_t* iters_traj, int32_t* status_any, void* stream);
+
 /* Diagnostics: when device_buf (DEVICE pointer, [max_batch][16] int64) is non-NULL every later solve
  * writes per-instance shader-clock stamps {setup, block algebra, dense sweeps, total, iters,
  * factorisations, -, -, iteration phases P0..P5, stop test + adaptation, -}; NULL switches it off

@@ -59,7 +59,7 @@ static inline double __hiloint2double(int hi, int lo) {
   const long long i = ((long long)hi << 32) | (unsigned)lo;
   double d; std::memcpy(&d, &i, 8); return d;
 }
-using std::fma; using std::fmin; using std::fmax;
+using std::fma; using std::fmin; using std::fmax; using std::fabs;
 
 namespace bmpc {
 static inline double rcp_approx(double x) { return 1.0 / x; }
@@ -93,7 +93,7 @@ namespace {
 template <int H>
 void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot, const uint8_t* contact,
            const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states, int32_t* iters,
-           float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg) {
+           float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg, const bmpc::WarmArgs& warm) {
   constexpr int NT = bmpc::Dims<H>::NT;
   for (int b = 0; b < B; ++b) {
     std::barrier<> bar(NT);
@@ -105,7 +105,7 @@ void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot
       th.emplace_back([&, t]() {
         threadIdx.x = t;
         blockIdx.x = b;
-        bmpc::solve_kernel<H>(P, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg);
+        bmpc::solve_kernel<H>(P, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
       });
     for (auto& x : th) x.join();
   }
@@ -125,10 +125,13 @@ bool inv3(const double* a, double* o) {
 
 }  // namespace
 
+extern "C" int bmpc_emu_threads(int h) { return h == 10 ? bmpc::Dims<10>::NT : (h == 16 ? bmpc::Dims<16>::NT : (h == 20 ? bmpc::Dims<20>::NT : -1)); }
+
 extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                               const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
                               int32_t* iters, float* resid, int32_t* status, int32_t* nfactor,
-                              double* dbg_x_ref, double* dbg_foot_ref, double* dbg_Gt, double* dbg_qt, int assemble_only) {
+                              double* dbg_x_ref, double* dbg_foot_ref, double* dbg_Gt, double* dbg_qt, int assemble_only,
+                              double* warm_buf, int warm_load, int warm_store, int warm_shift, double warm_theta) {
   bmpc::DevParams d;
   std::memset(&d, 0, sizeof(d));
   d.h = p->h; d.half = p->half; d.max_iter = p->max_iter; d.check_every = p->check_every;
@@ -144,10 +147,11 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.rho_hi_f = (float)p->rho_hi_f; d.rho_hi_m = (float)p->rho_hi_m;
   d.eps_pri = (float)p->eps_pri; d.eps_dua = (float)p->eps_dua; d.kappa = (float)p->kappa;
   bmpc::DebugOut dbg = {dbg_x_ref, dbg_foot_ref, dbg_Gt, dbg_qt, nullptr, assemble_only};
+  bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta};
   switch (p->h) {
-    case 10: run_h<10>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg); break;
-    case 16: run_h<16>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg); break;
-    case 20: run_h<20>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg); break;
+    case 10: run_h<10>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
+    case 16: run_h<16>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
+    case 20: run_h<20>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
     default: return -1;
   }
   return 0;

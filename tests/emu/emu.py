@@ -22,12 +22,19 @@ def build(force=False):
     return SO
 
 
+def threads(h):
+    lib = C.CDLL(build())
+    return int(lib.bmpc_emu_threads(int(h)))
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def solve(cparams, x_fb, foot, contact, phase, x_cmd=None, mu=None, assemble_only=False):
-    """Same marshalling as BatchSolver.solve / assemble.  Returns dict."""
+def solve(cparams, x_fb, foot, contact, phase, x_cmd=None, mu=None, assemble_only=False, warm=None, warm_load=False,
+          warm_shift=0, warm_theta=0.5):
+    """Same marshalling as BatchSolver.solve / assemble.  Returns dict.  `warm`: None, or a float64 array
+    (B, threads(h), 6) that receives the final solver state and, with warm_load, provides the start."""
     lib = C.CDLL(build())
     h = int(cparams.h)
     x_fb = np.ascontiguousarray(np.asarray(x_fb, np.float32).reshape(-1, 12))
@@ -41,11 +48,12 @@ def solve(cparams, x_fb, foot, contact, phase, x_cmd=None, mu=None, assemble_onl
                iters=np.zeros(B, np.int32), residuals=np.zeros((B, 2), np.float32), status=np.zeros(B, np.int32),
                nfactor=np.zeros(B, np.int32), x_ref=np.zeros((B, h, 12)), foot_ref=np.zeros((B, h, 6)),
                Gt=np.zeros((B, 6 * h, 6 * h)), qt=np.zeros((B, 6 * h)))
-    lib.bmpc_emu_solve.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 16 + [C.c_int]
+    lib.bmpc_emu_solve.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 16 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
     rc = lib.bmpc_emu_solve(C.byref(cparams), B, _ptr(x_fb), _ptr(foot), _ptr(contact), _ptr(phase), _ptr(x_cmd), _ptr(mu),
                             _ptr(out["controls"]), _ptr(out["states"]), _ptr(out["iters"]), _ptr(out["residuals"]),
                             _ptr(out["status"]), _ptr(out["nfactor"]), _ptr(out["x_ref"]), _ptr(out["foot_ref"]),
-                            _ptr(out["Gt"]), _ptr(out["qt"]), 1 if assemble_only else 0)
+                            _ptr(out["Gt"]), _ptr(out["qt"]), 1 if assemble_only else 0,
+                            _ptr(warm), 1 if warm_load else 0, 0 if warm is None else 1, int(warm_shift), float(warm_theta))
     if rc != 0:
         raise RuntimeError("bmpc_emu_solve failed")
     return out

@@ -37,3 +37,33 @@ def test_kernel_source_on_cpu_matches_fixtures(name, idx):
     if "x_ref" in d.files:                   # reference-captured references of these instances
         assert np.abs(o["x_ref"].transpose(0, 2, 1) - d["x_ref"][idx][:, :12]).max() < 1e-6
         assert np.abs(o["foot_ref"].transpose(0, 2, 1) - d["foot_ref"][idx]).max() < 1e-6
+
+
+def test_warm_start_same_optimum_on_cpu():
+    """Warm start (kernel source on the CPU): a second solve that starts from the state the first one left --
+    after the state feedback of one control period -- reaches the oracle's optimum of the NEW problem (the saving
+    in iterations is statistical: tests/test_gpu_parity.py measures it over a roll-out); a poisoned state buffer
+    (NaNs) is ignored."""
+    import __graft_entry__ as ge
+    ge.build()
+    import biped_mpc_py_amd as bm
+    from oracle import bmpc_oracle as orc
+    h = 10
+    s = util.synth_batch(1, h, 77)
+    mpc = bm.MPC()
+    cp = bm.pack_params(mpc, bm.Biped(), half=5)
+    warm = np.full((1, emu.threads(h), 6), np.nan)               # poisoned: the first solve must not read it
+    x0 = s["x_fb"].astype(np.float32)
+    o0 = emu.solve(cp, x0, s["foot"], s["contact"], s["phase"], warm=warm, warm_load=True, warm_theta=0.5)   # NaN state: cold
+    cold0 = emu.solve(cp, x0, s["foot"], s["contact"], s["phase"])
+    assert np.array_equal(o0["controls"], cold0["controls"]) and o0["iters"][0] == cold0["iters"][0]
+    assert np.isfinite(warm).all()
+    x1 = o0["states"][:, 0, :12].copy()                           # state feedback of one control period
+    o1 = emu.solve(cp, x1, s["foot"], s["contact"], s["phase"], warm=warm, warm_load=True, warm_theta=0.5)
+    cold1 = emu.solve(cp, x1, s["foot"], s["contact"], s["phase"])
+    _, ref = orc.solve_mpc(x1[0].astype(float), 0.0, s["foot"][0].astype(np.float32).astype(float), orc.MPC(), orc.Biped(),
+                           s["contact"][0])
+    assert (o1["status"] == 0).all()
+    assert util.rel_err(o1["controls"].astype(float), ref[None]).max() <= util.REL_TOL
+    assert util.rel_err(cold1["controls"].astype(float), ref[None]).max() <= util.REL_TOL
+    print("iterations: warm", o1["iters"][0], "cold", cold1["iters"][0])     # fewer on average, not for every instance

@@ -536,3 +536,56 @@ def test_bench_two_ranks_strong_scaling():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["total"] == 4099
     assert "bit-identical" in line["config"]["gather_check"]
     assert line["config"]["not_converged"] == 0
+
+
+@pytest.mark.parametrize("gait", ["standing", "walking"])
+def test_closed_loop_rollout_and_warm_start(gait):
+    """K = 20 control periods on the device (`bmpc_rollout_device`: schedule -> solve -> state
+    feedback, one stream, no host arithmetic) against the fp64 oracle's OWN closed loop on the same start states:
+    applied control and state agree per period to the north_star tolerance, with and without the receding-horizon
+    warm start (same optimum); the warm start needs fewer iterations."""
+    import torch
+    import biped_mpc_py_amd as bm
+    from oracle import bmpc_oracle as orc
+    B, K, h = 6, 20, 10
+    dev = torch.device("cuda", 0)
+    mpc, biped = bm.MPC(), bm.Biped()
+    rng = np.random.default_rng(5)
+    x0 = np.zeros((B, 12), np.float32)
+    x0[:, 5] = 0.55 + rng.uniform(-0.02, 0.02, B)
+    x0[:, 0:3] = rng.uniform(-0.03, 0.03, (B, 3))
+    x0[:, 9:12] = rng.uniform(-0.05, 0.05, (B, 3))
+    foot = np.tile(np.array([-0.0195, 0.089, 0, -0.0195, -0.089, 0], np.float32), (B, 1))
+    t0 = rng.uniform(0.0, 0.4, B)
+    duty = (10, 10) if gait == "standing" else None              # both legs in stance / the reference's schedule
+    # oracle closed loop
+    ref_u, ref_x = np.zeros((K, B, 12)), np.zeros((K, B, 12))
+    for b in range(B):
+        x, t = x0[b].astype(float), float(t0[b])
+        for k in range(K):
+            contact = np.ones((h, 2), int) if gait == "standing" else orc.get_contact_sequence(t, orc.MPC())
+            st, ct = orc.solve_mpc(x, t, foot[b].astype(float), orc.MPC(), orc.Biped(), contact)
+            ref_u[k, b], x = ct[0], st[0, :12]
+            ref_x[k, b] = x
+            t += mpc.dt
+    out = {}
+    for warm in (False, True):
+        s = bm.BatchSolver(mpc=mpc, biped=biped, max_batch=B)
+        if warm:
+            s.set_warm_start(True, shift=(0 if gait == "standing" else 1), theta=0.5)
+        x = torch.from_numpy(x0.copy()).to(dev)
+        t = torch.from_numpy(t0.copy()).to(dev)
+        r = s.rollout_device(x, torch.from_numpy(foot).to(dev), t, K, period=(10 if duty else None), duty=duty)
+        torch.cuda.synchronize()
+        assert int((r["status_any"] != 0).sum()) == 0
+        u, xs = r["u0"].cpu().numpy().astype(float), r["x"].cpu().numpy().astype(float)
+        eu = np.abs(u - ref_u).max(2) / np.maximum(1.0, np.abs(ref_u).max(2))
+        ex = np.abs(xs - ref_x).max(2) / np.maximum(1.0, np.abs(ref_x).max(2))
+        out[warm] = r["iters"].cpu().numpy()
+        print(gait, "warm" if warm else "cold", "u0 err max %.2e  x err max %.2e  mean iters %.1f (periods 2..K: %.1f)" %
+              (eu.max(), ex.max(), out[warm].mean(), out[warm][1:].mean()))
+        assert eu.max() <= util.REL_TOL and ex.max() <= util.REL_TOL
+        assert np.allclose(t.cpu().numpy(), t0 + K * mpc.dt)
+        s.close()
+    assert np.array_equal(out[True][0], out[False][0])             # the first period starts cold either way
+    assert out[True][1:].mean() < 0.9 * out[False][1:].mean()
