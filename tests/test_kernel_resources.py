@@ -35,3 +35,38 @@ def test_no_spills_and_two_waves_per_simd(tmp_path):
         lds = int(meta["group_segment_fixed_size"])
         waves = {10: 2, 16: 3, 20: 4}[h]
         assert (160 * 1024 // lds) * waves >= 8, (h, lds)                     # LDS lets 8 waves live on a CU
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
+def test_no_dpp_hazard_behind_inline_asm(tmp_path):
+    """The broadcast FMAs are inline-asm `v_fmac_f32_dpp`; the compiler's hazard recogniser does not look inside
+    inline asm, so nothing inserts the two wait states a DPP read needs after a VALU write of the same register.
+    The kernels feed them from LDS loads only; this test scans the generated ISA to make sure no vector
+    instruction writes a DPP source register within the two instructions before its DPP read."""
+    import __graft_entry__ as ge
+    out = str(tmp_path / "bmpc.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "--cuda-device-only", "-S", os.path.join(ge.CSRC, "bmpc_capi.hip"), "-o", out] + ge.KERNEL_FLAGS,
+                          cwd=ge.CSRC, stderr=subprocess.DEVNULL)
+    lines = [ln.split(";")[0].strip() for ln in open(out).read().splitlines()]
+    lines = [ln for ln in lines if ln and not ln.startswith(".") and not ln.endswith(":")]
+
+    def written(ln):
+        parts = ln.split(None, 1)
+        if len(parts) < 2 or not parts[0].startswith("v_"):
+            return set()
+        dst = parts[1].split(",")[0].strip()
+        m = re.match(r"v\[(\d+):(\d+)\]", dst)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", dst)
+        return {int(m.group(1))} if m else set()
+
+    n = 0
+    for i, ln in enumerate(lines):
+        if ln.startswith("v_fmac_f32_dpp"):
+            n += 1
+            src = int(re.findall(r"v(\d+)", ln)[1])
+            for k in (1, 2):
+                assert src not in written(lines[i - k]), (lines[i - k], ln)
+    assert n > 300          # the sweep and the V mat-vec of three horizons
