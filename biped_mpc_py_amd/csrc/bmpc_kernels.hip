@@ -59,6 +59,7 @@ __device__ __forceinline__ void fmac_bcast(float& acc, float src, float mul) {
 __device__ __forceinline__ void bcast_sync() {}
 #define BMPC_BCAST_PUBLISH_ALL(RA, RB, NR) do { } while (0)
 #define BMPC_FENCE() asm volatile("" ::: "memory")
+#define BMPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across
 // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
 // redone there instead of being hoisted into a second, f64, register copy that lives across the loop
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
@@ -119,15 +120,22 @@ struct Dims {
   static constexpr int GH = ((3 * HH + 3) / 4) * 4;
   static constexpr int GS = (GH % 16 == 0 && GH % 64 != 16 && GH % 64 != 48) ? GH + 4 : GH;   // stride of the 4 gamma copies
 };
-// V[I] += x_A[I] m0 (+ x_B[I] m1) for I in [I0, I1): x_A[I] is register RA[I / 16] of lane I % 16 of the row of 16
+// V[I] += x[I] m for I in [I0, I1): x[I] is register R[I / 16] of lane I % 16 of the row of 16 (KB: the first
+// emulation plane of R).  One pass per source vector, so that consecutive FMAs are independent.
+template <int I0, int I1, int HN, int NR, int KB>
+struct BcastAxpy {
+  static __device__ __forceinline__ void run(float (&V)[HN], const float (&R)[NR], float m) {
+    if constexpr (I0 < I1) {
+      fmac_bcast<KB + I0 / 16, I0 % 16>(V[I0], R[I0 / 16], m);
+      BcastAxpy<I0 + 1, I1, HN, NR, KB>::run(V, R, m);
+    }
+  }
+};
 template <int I0, int I1, int HN, int NR, bool TWO>
 struct BcastUpdate {
   static __device__ __forceinline__ void run(float (&V)[HN], const float (&RA)[NR], const float (&RB)[NR], float m0, float m1) {
-    if constexpr (I0 < I1) {
-      fmac_bcast<I0 / 16, I0 % 16>(V[I0], RA[I0 / 16], m0);
-      if constexpr (TWO) fmac_bcast<NR + I0 / 16, I0 % 16>(V[I0], RB[I0 / 16], m1);
-      BcastUpdate<I0 + 1, I1, HN, NR, TWO>::run(V, RA, RB, m0, m1);
-    }
+    BcastAxpy<I0, I1, HN, NR, 0>::run(V, RA, m0);
+    if constexpr (TWO) BcastAxpy<I0, I1, HN, NR, NR>::run(V, RB, m1);
   }
 };
 // acc[I % 4] += x[I] V[I] for I in [I0, I1)
@@ -248,15 +256,20 @@ __device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64])
 // reads each) and the six outputs accumulate as independent chains.
 __device__ __forceinline__ void row_times_mat6(const double (&w)[6], const double (*M)[6], double (&out)[6]) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    double row[6];
+  for (int q0 = 0; q0 < 6; q0 += 3) {           // three rows (nine 16-byte reads) in flight, then their FMAs
+    double rw[3][6];
 #pragma unroll
-    for (int b = 0; b < 6; b += 2) {
-      const double2 v = *reinterpret_cast<const double2*>(&M[q][b]);
-      row[b] = v.x; row[b + 1] = v.y;
-    }
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
-    for (int b = 0; b < 6; ++b) out[b] = fma(w[q], row[b], out[b]);
+      for (int b = 0; b < 6; b += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&M[q0 + q][b]);
+        rw[q][b] = v.x; rw[q][b + 1] = v.y;
+      }
+    BMPC_SCHED_BARRIER();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) out[b] = fma(w[q0 + q], rw[q][b], out[b]);
   }
 }
 
@@ -894,12 +907,13 @@ solve_kernel(const DevParams P, const int B,
         float* nA = sm.piv[par ^ 1];
         par ^= 1;
         __syncthreads();
-        float RA[NR], RB[NR];                            // this lane's share of the two pivot rows (own half)
-#pragma unroll
-        for (int k = 0; k < NR; ++k) { RA[k] = bA[hf * HNP + 16 * k + ln]; RB[k] = bB[hf * HNP + 16 * k + ln]; }
         const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
         const float p11 = bB[u + 1];
         const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
+        float RA[NR], RB[NR];                            // this lane's share of the two pivot rows (own half)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { RA[k] = bA[hf * HNP + 16 * k + ln]; RB[k] = bB[hf * HNP + 16 * k + ln]; }
+        BMPC_SCHED_BARRIER();                            // every load of the step is in flight before the first use
         const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
         const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
         const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
@@ -1070,14 +1084,18 @@ solve_kernel(const DevParams P, const int B,
       sm.u.itv.wg[j][f][c] = yg + widen(rvg) * (axg - zg);
       sm.u.itv.gb[row] = gbl;                 // both lanes carry the same value
     }
+    // what P2 needs of the per-factorisation data is fetched before the barrier: its latency overlaps the wait
+    float lcol[6];
+    RT gut[6], rx0, rx1;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
+    rx0 = sm.rx[j][f][c][0]; rx1 = sm.rx[j][f][c][1];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f].d[j][i][c][0];
     __syncthreads();
     BMPC_STAMP(0)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
-    float lcol[6];
     if (valid) {
-      RT gut[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) gut[q] = sm.GuT[c][q];
       // W_f' g for this lane's variable: force variable a gets (g_tau x r_f)_a + g_F[a], moment variable a gets
       // g_tau[a].  One straight line for all lanes: the cyclic neighbours of a are picked by address, the lever
       // arm components come from a per-lane table that is zero for moment variables.
@@ -1085,17 +1103,24 @@ solve_kernel(const DevParams P, const int B,
       const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
       const RT g1 = sm.u.itv.gb[6 * j + i1], g2 = sm.u.itv.gb[6 * j + i2];
       const RT gsel = sm.u.itv.gb[6 * j + (c < 3 ? c + 3 : c - 3)];
-      RT r = widen(R2v) * xo + wb;
       RT wq[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) wq[q] = sm.u.itv.wg[j][f][q];
+      // (every load of the phase is issued before the first dependent instruction: left to itself the
+      // scheduler sinks each load next to its use and the phase pays one LDS round trip per load group)
+      BMPC_SCHED_BARRIER();
+      RT r = widen(R2v) * xo + wb;
 #pragma unroll
       for (int q = 0; q < 6; ++q) r += gut[q] * wq[q];
       r += widen(cmu) * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
-      const RT wt = g1 * sm.rx[j][f][c][0] - g2 * sm.rx[j][f][c][1] + gsel;
+      const RT wt = g1 * rx0 - g2 * rx1 + gsel;
       sm.u.itv.r32[j][f][c] = (float)(r + wt);
+    }
+    f2 kg[6], lg[6];                           // rows c of {Kn, G Kn} and {L, G L} of the own foot (for P5; fetched early)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f].d[j][i][c][0];
+    for (int i = 0; i < 6; ++i) {
+      kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
+      lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
     }
     __syncthreads();
     BMPC_STAMP(2)
@@ -1110,11 +1135,28 @@ solve_kernel(const DevParams P, const int B,
           const float2 v = *reinterpret_cast<const float2*>(&sm.u.itv.r32[j][ft][i]);
           rj[ft][i] = v.x; rj[ft][i + 1] = v.y;
         }
+      BMPC_SCHED_BARRIER();
 #pragma unroll
       for (int i = 0; i < 6; ++i) bsum = fmaf(lcol[i], f == 0 ? rj[0][i] : rj[1][i], bsum);
     }
     bsum += pair_swap(bsum);
     sm.u.itv.beta[slot<H>(row)] = bsum * dsc;   // both lanes of the pair: same value (a + b == b + a)
+    // the part of the step that does not need gamma (off the critical path, before the barrier):
+    // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
+    f2 ddk = {0.f, 0.f};
+    {
+      float tn[6];
+      const float d0 = drf[0], d1 = drf[1], d2 = drf[2];
+      tn[0] = rj[0][0] - rj[1][0] + (d1 * rj[1][5] - d2 * rj[1][4]);
+      tn[1] = rj[0][1] - rj[1][1] + (d2 * rj[1][3] - d0 * rj[1][5]);
+      tn[2] = rj[0][2] - rj[1][2] + (d0 * rj[1][4] - d1 * rj[1][3]);
+      tn[3] = rj[0][3] - rj[1][3];
+      tn[4] = rj[0][4] - rj[1][4];
+      tn[5] = rj[0][5] - rj[1][5];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ddk = __builtin_elementwise_fma(kg[i], f2{tn[i], tn[i]}, ddk);
+      if (f == 1) ddk = -ddk;
+    }
     __syncthreads();
     BMPC_STAMP(3)
     // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S).  beta reaches the
@@ -1124,6 +1166,7 @@ solve_kernel(const DevParams P, const int B,
       float RB4[NR];
 #pragma unroll
       for (int k = 0; k < NR; ++k) RB4[k] = sm.u.itv.beta[hf * HNP + 16 * k + ln];
+      BMPC_SCHED_BARRIER();
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       BMPC_BCAST_PUBLISH_ALL(RB4, RB4, NR);
       bcast_sync();
@@ -1151,29 +1194,24 @@ solve_kernel(const DevParams P, const int B,
         const float2 v = *reinterpret_cast<const float2*>(&sm.u.itv.gam[6 * j + i]);
         gm[i] = v.x; gm[i + 1] = v.y;
       }
-      f2 kg[6], lg[6];                         // rows c of {Kn, G Kn} and {L, G L} of the own foot
+      // gradient increment operands (4 loads) with the gamma loads, before anything is used
+      const float* gsrc = &sm.u.itv.gamT[(c < 3 ? 0 : 2) + hf][0];
+      constexpr int NG = 3 * HH;
+      float gq[NG];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
-        lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
+      for (int q = 0; q + 4 <= NG; q += 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(&gsrc[q]);
+        gq[q] = g4.x; gq[q + 1] = g4.y; gq[q + 2] = g4.z; gq[q + 3] = g4.w;
       }
-      // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
-      float tn[6];
-      {
-        const float d0 = drf[0], d1 = drf[1], d2 = drf[2];
-        tn[0] = rj[0][0] - rj[1][0] + (d1 * rj[1][5] - d2 * rj[1][4]);
-        tn[1] = rj[0][1] - rj[1][1] + (d2 * rj[1][3] - d0 * rj[1][5]);
-        tn[2] = rj[0][2] - rj[1][2] + (d0 * rj[1][4] - d1 * rj[1][3]);
-        tn[3] = rj[0][3] - rj[1][3];
-        tn[4] = rj[0][4] - rj[1][4];
-        tn[5] = rj[0][5] - rj[1][5];
+      if constexpr (NG % 4 >= 2) {
+        const float2 g2 = *reinterpret_cast<const float2*>(&gsrc[NG / 4 * 4]);
+        gq[NG / 4 * 4] = g2.x; gq[NG / 4 * 4 + 1] = g2.y;
       }
+      if constexpr (NG % 2 == 1) gq[NG - 1] = gsrc[NG - 1];
+      BMPC_SCHED_BARRIER();
       RT st_pb, st_pg, st_x, st_g, st_dx;     // residual statistics inputs (used at stopping tests)
       {
-        f2 dd = {0.f, 0.f};                     // {d_f[c], (G_f d_f)[c]}
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(kg[i], f2{tn[i], tn[i]}, dd);
-        if (f == 1) dd = -dd;
+        f2 dd = ddk;                            // {d_f[c], (G_f d_f)[c]}: the null-space part was formed in P3
 #pragma unroll
         for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(lg[i], f2{gm[i], gm[i]}, dd);
         const float s = dd.x, sg = dd.y;
@@ -1206,21 +1244,16 @@ solve_kernel(const DevParams P, const int B,
       {
         // exactly the 3 HH entries that were written: the padding of gamT is never initialised (and the
         // factorisation scratch shares its LDS), 0 x garbage could be a NaN
-        const float* gsrc = &sm.u.itv.gamT[(c < 3 ? 0 : 2) + hf][0];
         f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
-        constexpr int NG = 3 * HH;
 #pragma unroll
         for (int q = 0; q + 4 <= NG; q += 4) {
-          const float4 g4 = *reinterpret_cast<const float4*>(&gsrc[q]);
-          e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{g4.x, g4.y}, e0);
-          e1 = __builtin_elementwise_fma(f2{Grow[q + 2], Grow[q + 3]}, f2{g4.z, g4.w}, e1);
+          e0 = __builtin_elementwise_fma(f2{Grow[q], Grow[q + 1]}, f2{gq[q], gq[q + 1]}, e0);
+          e1 = __builtin_elementwise_fma(f2{Grow[q + 2], Grow[q + 3]}, f2{gq[q + 2], gq[q + 3]}, e1);
         }
-        if constexpr (NG % 4 >= 2) {
-          const float2 g2 = *reinterpret_cast<const float2*>(&gsrc[NG / 4 * 4]);
-          e0 = __builtin_elementwise_fma(f2{Grow[NG / 4 * 4], Grow[NG / 4 * 4 + 1]}, f2{g2.x, g2.y}, e0);
-        }
+        if constexpr (NG % 4 >= 2)
+          e0 = __builtin_elementwise_fma(f2{Grow[NG / 4 * 4], Grow[NG / 4 * 4 + 1]}, f2{gq[NG / 4 * 4], gq[NG / 4 * 4 + 1]}, e0);
         float etail = 0.f;
-        if constexpr (NG % 2 == 1) etail = Grow[NG - 1] * gsrc[NG - 1];
+        if constexpr (NG % 2 == 1) etail = Grow[NG - 1] * gq[NG - 1];
         ginc = ((e0.x + e0.y) + (e1.x + e1.y)) + etail;
       }
       if (check_now) {

@@ -90,6 +90,7 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
 }  // namespace bmpc
 #define BMPC_FENCE() do { } while (0)
 #define BMPC_OPAQUE(x) do { } while (0)
+#define BMPC_SCHED_BARRIER() do { } while (0)
 
 #include "../../biped_mpc_py_amd/csrc/bmpc_kernels.hip"
 #include "bmpc.h"
