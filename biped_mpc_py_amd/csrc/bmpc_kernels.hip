@@ -106,6 +106,9 @@ struct Dims {
   static constexpr int HH = H / 2;                       // steps per column half
   static constexpr int NT = ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
   static constexpr int NWV = NT / 64;
+  // waves per SIMD the register allocation aims at: instances are latency-bound chains of LDS exchanges, so the
+  // throughput of a CU is (instances in flight) / (latency of one), and a third wave per SIMD is worth some spills
+  static constexpr int WPE = H <= 16 ? 3 : 2;
   static constexpr int NPAIR = H * (H - 1) / 2;          // (i > j) step pairs
   // A vector over the wrench rows that both column halves read is stored in LDS as two 16-byte aligned
   // halves: entry i sits at slot(i).  The halves start 4 k dwords apart with 4 k mod 64 outside (-4, 4), so
@@ -332,7 +335,7 @@ __device__ __forceinline__ void general_rows(float mu, const float* ey, const fl
 }
 
 template <int H>
-__global__ void __launch_bounds__(Dims<H>::NT, 2)
+__global__ void __launch_bounds__(Dims<H>::NT, Dims<H>::WPE)
 solve_kernel(const DevParams P, const int B,
              const float* __restrict__ x_fb, const float* __restrict__ foot,
              const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase,
@@ -1077,6 +1080,17 @@ solve_kernel(const DevParams P, const int B,
       need_factor = false;
     }
     if (dbg.prof) t_last = clock64();
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
+    const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
+    float ginc = 0.f;
+    {
+    // The lane's indices are re-materialised (opaque copies) in every iteration: some forty LDS addresses
+    // derived from them are loop invariant, and hoisted out of the loop each of them holds a register across
+    // the factorisation and the iterations -- the registers that decide how many waves share a SIMD.
+    const int j_q = j, c_q = c, f_q = f, hf_q = hf, row_q = row, ln_q = ln;
+    {
+    int j = j_q, c = c_q, f = f_q, hf = hf_q, row = row_q, ln = ln_q;
+    BMPC_OPAQUE(j); BMPC_OPAQUE(c); BMPC_OPAQUE(f); BMPC_OPAQUE(hf); BMPC_OPAQUE(row); BMPC_OPAQUE(ln);
     // --- P0: row residuals w = y + rho (A x - z); publish them and the gradient
     RT wb = 0;
     if (valid) {
@@ -1184,9 +1198,6 @@ solve_kernel(const DevParams P, const int B,
     __syncthreads();
     BMPC_STAMP(4)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
-    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
-    const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
-    float ginc = 0.f;
     if (valid) {
       float gm[6];
 #pragma unroll
@@ -1265,6 +1276,8 @@ solve_kernel(const DevParams P, const int B,
         // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
         nx = (st_x == st_x) ? fabsf((float)st_x) : __builtin_inff();
       }
+    }
+    }
     }
     ginc += pair_swap(ginc);
     gbl -= alpha * (RT)ginc;
