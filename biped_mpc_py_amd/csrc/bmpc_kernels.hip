@@ -13,9 +13,8 @@
 //   solve            the unique minimiser REF:297 asks cvxopt for, by ADMM with active-set adaptive
 //                    penalties; unpack controls / states (REF:300-304)
 //
-// Thread map: TWO lanes per wrench row.  Lane l  <->  (row = 16 (l / 32) + l % 16, half hf = (l / 16) % 2), row =
-// (step j = row / 6, component c = row % 6): a row of 16 lanes holds 16 consecutive wrench rows of one half, the
-// two lanes of a wrench row sit 16 apart and exchange through the LDS crossbar (ds_swizzle: no memory, no
+// Thread map: TWO lanes per wrench row.  Lane l  <->  (row = l / 2, half hf = l % 2), row = (step j = row / 6,
+// component c = row % 6).  The two lanes of a row are neighbours, so they exchange through DPP (no LDS, no
 // barrier).  Between them they split
 //   * the row of V = (Gt + F)^-1 and of Gt by COLUMN halves: lane hf holds the columns of steps
 //     [hf H/2, (hf + 1) H/2) -- half the sweep, half the mat-vecs, half the registers each,
@@ -45,19 +44,8 @@ typedef double RT;                       // iterate / residual / block-algebra a
 __device__ __forceinline__ double rcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
 __device__ __forceinline__ float rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq_approx(float x) { return __builtin_amdgcn_rsqf(x); }
-// value of the other lane of the pair (lane ^ 16: the same position in the neighbouring row of 16 lanes) through
-// the LDS crossbar (ds_swizzle SWAP 16: no memory access).  Call with all lanes active.
-__device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x401F); }
-// acc += x * mul, x = `src` of lane N of the caller's row of 16 lanes (DPP row_newbcast): an operand that 16 lanes
-// share reaches the FMA without 16 copies of it being fetched from LDS.  `src` must come from a load, not from
-// a vector instruction just before (the DPP read-after-VALU-write hazard is not tracked through inline asm).
-// K names the source register for the CPU emulation only.
-template <int K, int N>
-__device__ __forceinline__ void fmac_bcast(float& acc, float src, float mul) {
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
-}
-__device__ __forceinline__ void bcast_sync() {}
-#define BMPC_BCAST_PUBLISH_ALL(RA, RB, NR) do { } while (0)
+// value of the other lane of the pair (lane ^ 1): DPP quad_perm [1, 0, 3, 2].  Call with all lanes active.
+__device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
 #define BMPC_FENCE() asm volatile("" ::: "memory")
 #define BMPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across
 // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
@@ -106,52 +94,24 @@ struct Dims {
   static constexpr int HH = H / 2;                       // steps per column half
   static constexpr int NT = ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
   static constexpr int NWV = NT / 64;
-  // waves per SIMD the register allocation aims at: instances are latency-bound chains of LDS exchanges, so the
-  // throughput of a CU is (instances in flight) / (latency of one), and a third wave per SIMD is worth some spills
-  static constexpr int WPE = H <= 16 ? 3 : 2;
+  // Waves per SIMD the register allocation aims at.  An instance is a latency-bound chain of LDS exchanges, so a
+  // CU's throughput is (instances in flight) / (latency of one); two per SIMD = 4 instances per CU at h = 10.
+  // Three per SIMD (<= 168 registers) was measured with the DPP-broadcast variant of this kernel (DESIGN.md
+  // section 9): 5 instances per CU at h = 10 gained nothing at the 4096-instance batch (the vector pipe was
+  // then ~80 % busy), h = 16 gained 11 %; this variant needs too many spills for it (155 at h = 16).
+  static constexpr int WPE = 2;
   static constexpr int NPAIR = H * (H - 1) / 2;          // (i > j) step pairs
   // A vector over the wrench rows that both column halves read is stored in LDS as two 16-byte aligned
   // halves: entry i sits at slot(i).  The halves start 4 k dwords apart with 4 k mod 64 outside (-4, 4), so
   // the two addresses of a wave's ds_read_b128 (even lanes: half 0, odd lanes: half 1) never share a bank.
   static constexpr int HNP = ((HN + 3) / 4) * 4;
   static constexpr int VL = 2 * HNP;
-  // ... plus what the 16-lane-wide register loads of the second half read past its end
-  static constexpr int VLR = VL > HNP + 16 * ((HN + 15) / 16) ? VL : HNP + 16 * ((HN + 15) / 16);
-  static constexpr int PVS = ((VLR + NW + 3) / 4) * 4;    // one published pivot column: two-half vector + one dump slot per row
+  static constexpr int PVS = ((VL + NW + 3) / 4) * 4;    // one published pivot column: two-half vector + one dump slot per row
   static_assert(HNP % 64 >= 4 && HNP % 64 <= 60, "halves of a two-half vector would collide on LDS banks");
   // Gt row half: 3 component groups x HH steps, padded to whole float4s
   static constexpr int GH = ((3 * HH + 3) / 4) * 4;
   static constexpr int GS = (GH % 16 == 0 && GH % 64 != 16 && GH % 64 != 48) ? GH + 4 : GH;   // stride of the 4 gamma copies
 };
-// V[I] += x[I] m for I in [I0, I1): x[I] is register R[I / 16] of lane I % 16 of the row of 16 (KB: the first
-// emulation plane of R).  One pass per source vector, so that consecutive FMAs are independent.
-template <int I0, int I1, int HN, int NR, int KB>
-struct BcastAxpy {
-  static __device__ __forceinline__ void run(float (&V)[HN], const float (&R)[NR], float m) {
-    if constexpr (I0 < I1) {
-      fmac_bcast<KB + I0 / 16, I0 % 16>(V[I0], R[I0 / 16], m);
-      BcastAxpy<I0 + 1, I1, HN, NR, KB>::run(V, R, m);
-    }
-  }
-};
-template <int I0, int I1, int HN, int NR, bool TWO>
-struct BcastUpdate {
-  static __device__ __forceinline__ void run(float (&V)[HN], const float (&RA)[NR], const float (&RB)[NR], float m0, float m1) {
-    BcastAxpy<I0, I1, HN, NR, 0>::run(V, RA, m0);
-    if constexpr (TWO) BcastAxpy<I0, I1, HN, NR, NR>::run(V, RB, m1);
-  }
-};
-// acc[I % 4] += x[I] V[I] for I in [I0, I1)
-template <int I0, int I1, int HN, int NR>
-struct BcastDot {
-  static __device__ __forceinline__ void run(float (&acc)[4], const float (&V)[HN], const float (&R)[NR]) {
-    if constexpr (I0 < I1) {
-      fmac_bcast<I0 / 16, I0 % 16>(acc[I0 % 4], R[I0 / 16], V[I0]);
-      BcastDot<I0 + 1, I1, HN, NR>::run(acc, V, R);
-    }
-  }
-};
-
 template <int H>
 __device__ __forceinline__ constexpr int slot(int i) { return i < Dims<H>::HN ? i : i - Dims<H>::HN + Dims<H>::HNP; }
 
@@ -171,7 +131,7 @@ struct IterScratch {
   alignas(16) RT bwT[6][H];  // net wrench of x, component-major: a lane reads its inputs of Gt contiguously
   RT gb[NW];                 // wrench-space gradient Gt b + qt
   alignas(16) float r32[H][2][6];   // KKT residual, control space
-  alignas(16) float beta[Dims<H>::VLR];  // d .* L' r, two-half layout
+  alignas(16) float beta[Dims<H>::VL];   // d .* L' r, two-half layout
   alignas(16) float gam[NW];
   // gamma again for the gradient increment: per (component group = torque / force, column half) the 3 HH
   // values a lane multiplies with its Gt row half, contiguous, zero padded to GH
@@ -364,15 +324,14 @@ solve_kernel(const DevParams P, const int B,
 #define BMPC_STAMP(k) if (dbg.prof) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
   if (dbg.prof) t_start = clock64();
   const int l = threadIdx.x;
-  const int hf = (l >> 4) & 1;                 // column half of V / Gt, and the foot this lane owns
+  const int hf = l & 1;                        // column half of V / Gt, and the foot this lane owns
   const int f = hf;
-  const int ln = l & 15;                       // position in the row of 16 lanes (DPP broadcasts)
   // The lanes past the last row (8 at h = 10, 16 at h = 20) CLONE the last row: same indices, same data, same
   // arithmetic, so their LDS writes repeat the real lane's values at the real lane's addresses and nothing has
   // to be predicated (every `if (lane is real)` would be an exec-mask branch, and the code sinking across such
   // branches is what blew up the sweep's register pressure); only their global stores are suppressed.
-  const bool real = (16 * (l >> 5) + ln) < NW;
-  const int row = real ? 16 * (l >> 5) + ln : NW - 1;
+  const bool real = (l >> 1) < NW;
+  const int row = real ? (l >> 1) : NW - 1;
   constexpr bool valid = true;
   const int j = row / 6;
   const int c = row % 6;
@@ -648,10 +607,9 @@ solve_kernel(const DevParams P, const int B,
   RT irvb = (RT)1 / (RT)rvb, irvg = (RT)1 / (RT)rvg;  // reciprocals (refreshed with the penalties)
   // Half a row of -(S (Gt + F) S)^-1 after the sweep (S = Jacobi scaling to unit diagonal), as float pairs:
   // the sweep and the V mat-vec run on the packed-f32 pipe (v_pk_fma_f32: two f32 per lane and instruction)
-  float Vr[HN];
+  f2 Vr[HN / 2];
   float dsc = 1.f;                            // S[row]
-#define VROW(q) Vr[q]
-  constexpr int NR = (HN + 15) / 16;          // registers that hold a vector over the column half, 16 lanes wide
+#define VROW(q) Vr[(q) >> 1][(q) & 1]
 
   auto factor = [&]() {
     if (dbg.prof) t_mark = clock64();
@@ -871,92 +829,109 @@ solve_kernel(const DevParams P, const int B,
       for (int b = 0; b < 6; ++b) VROW(6 * jj + b) = fmaf(mj, fv[b], VROW(6 * jj + b));
     }
     __syncthreads();
+    {
+      const f2 d2 = {dsc, dsc};
 #pragma unroll
-    for (int q = 0; q < HN; q += 2) {
-      const float2 s2 = *reinterpret_cast<const float2*>(&sm.dsc[hf * HNP + q]);
-      Vr[q] *= dsc * s2.x;
-      Vr[q + 1] *= dsc * s2.y;
+      for (int q = 0; q < HN; q += 4) {
+        if (q + 4 <= HN) {
+          const float4 s4 = *reinterpret_cast<const float4*>(&sm.dsc[hf * HNP + q]);
+          Vr[q / 2] = Vr[q / 2] * d2 * f2{s4.x, s4.y};
+          Vr[q / 2 + 1] = Vr[q / 2 + 1] * d2 * f2{s4.z, s4.w};
+        } else {
+          const float2 s2 = *reinterpret_cast<const float2*>(&sm.dsc[hf * HNP + q]);
+          Vr[q / 2] = Vr[q / 2] * d2 * f2{s2.x, s2.y};
+        }
+      }
     }
     // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of half hf
-    // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always two static registers
+    // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always one static register pair
     // of the half-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the half-0 lanes publish their two entries of the
-    // pivot columns (= pivot rows, by symmetry).  A row of 16 lanes needs the HN entries of ITS half of the two
-    // pivot rows: each lane fetches 2 x NR of them (instead of all 2 HN), and the updates read them from the
-    // owning lane by DPP row broadcast:  V[i] -= T[r, 0] row_k[i] + T[r, 1] row_k+1[i],  T[r, :] = V[r, S] P^-1;
-    // the pivot rows themselves use T[r, :] = e_r - P^-1[r, :], which turns them into P^-1 V[S, :] (exact up to
-    // rounding because the scaled pivots are <= 1; no second multiply, and a row is never rebuilt from a column
-    // -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).  The entries in the columns S
-    // become T (V[r, S] P^-1) and, in the pivot block, -P^-1.
-    // The update of the NEXT pair of pivot columns is done first and published at once (into the other
-    // buffer), so that its round trip through LDS overlaps with the rest of this step's updates.
+    // pivot columns (= pivot rows, by symmetry), every lane fetches the 2 HN entries of its half, forms its
+    // T[r, :] = V[r, S] P^-1 and updates with TWO packed FMAs per register pair:  row -= T[r, 0] row_k +
+    // T[r, 1] row_k+1; the pivot rows themselves use T[r, :] = e_r - P^-1[r, :], which turns them into
+    // P^-1 V[S, :] (exact up to rounding because the scaled pivots are <= 1; no second multiply, and a row is
+    // never rebuilt from a column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
+    // The entries in the columns S become T (V[r, S] P^-1) and, in the pivot block, -P^-1.
+    // Two pivots per barrier and LDS round trip instead of one; the update of the NEXT pair of pivot columns
+    // is done first and published at once (into the other buffer), so that its round trip overlaps with the
+    // rest of this step's updates.
     constexpr int U = 6;
-    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= 16, "sweep group must divide 6H, be even and lie in one register");
+    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
     constexpr int PVS = Dims<H>::PVS;            // floats per published column (two-half layout + dump slots)
     int pos = row;                              // rotated index of the own row (group 0)
-    int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VLR + row;
-    sm.piv[0][ws] = Vr[0];
-    sm.piv[0][PVS + ws] = Vr[1];
+    int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
+    sm.piv[0][ws] = Vr[0].x;
+    sm.piv[0][PVS + ws] = Vr[0].y;
     int par = 0;                                // buffer of the current step (a group has an odd number of steps)
 #pragma unroll 1
     for (int k0 = 0; k0 < NW; k0 += U) {
       const int ps = slot<H>(pos);
       int posn = pos - U;                       // ... and in the next group
       posn += (posn < 0) ? NW : 0;
-      const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VLR + row;
+      const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
 #pragma unroll
       for (int u = 0; u < U; u += 2) {
         const float* bA = sm.piv[par];                   // column k
         const float* bB = bA + PVS;                      // column k + 1
         float* nA = sm.piv[par ^ 1];
         par ^= 1;
+        const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
         __syncthreads();
         const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
         const float p11 = bB[u + 1];
         const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
-        float RA[NR], RB[NR];                            // this lane's share of the two pivot rows (own half)
-#pragma unroll
-        for (int k = 0; k < NR; ++k) { RA[k] = bA[hf * HNP + 16 * k + ln]; RB[k] = bB[hf * HNP + 16 * k + ln]; }
-        BMPC_SCHED_BARRIER();                            // every load of the step is in flight before the first use
+        BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
         const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
         const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
         const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
         float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
         t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
         t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
-        const float m0 = -t0, m1 = -t1;
-        BMPC_BCAST_PUBLISH_ALL(RA, RB, NR);
-        bcast_sync();
-        // the next pair of pivot columns first (u + 2 == U: the first pair of the next group), then the rest
-        if (u == 0) {
-          BcastUpdate<2, 4, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-          nA[ws] = Vr[2]; nA[PVS + ws] = Vr[3];
-          BcastUpdate<0, 2, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-          BcastUpdate<4, HN, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-        } else if (u == 2) {
-          BcastUpdate<4, 6, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-          nA[ws] = Vr[4]; nA[PVS + ws] = Vr[5];
-          BcastUpdate<0, 4, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-          BcastUpdate<6, HN, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-        } else {
-          BcastUpdate<6, 8, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-          nA[wsn] = Vr[6]; nA[PVS + wsn] = Vr[7];    // (after the very last step: columns nobody reads)
-          BcastUpdate<0, 6, HN, NR, true>::run(Vr, RA, RB, m0, m1);
-          BcastUpdate<8, HN, HN, NR, true>::run(Vr, RA, RB, m0, m1);
+        const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
+        // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the
+        // next pivot columns first
+        constexpr int CH = HN <= 32 ? HN : 16;
+        static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
+#pragma unroll
+        for (int c0i = 0; c0i < HN; c0i += CH) {
+          const int c1i = c0i + CH < HN ? c0i + CH : HN;
+          f2 pa[CH / 2], pb[CH / 2];
+#pragma unroll
+          for (int q = c0i; q < c1i; q += 4) {
+            if (q + 4 <= c1i) {
+              const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
+              const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
+              pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
+            } else {
+              const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
+              const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a2.x, a2.y};
+              pb[(q - c0i) / 2] = f2{b2.x, b2.y};
+            }
+          }
+          if (c0i == 0) {
+            static_assert(U / 2 + 1 <= CH / 2, "the next pivot pair lies in the first chunk");
+            Vr[un] = __builtin_elementwise_fma(m1, pb[un], __builtin_elementwise_fma(m0, pa[un], Vr[un]));
+            const int wn = u + 2 < U ? ws : wsn;         // (after the very last step: columns nobody reads)
+            nA[wn] = Vr[un].x;
+            nA[PVS + wn] = Vr[un].y;
+          }
+#pragma unroll
+          for (int r = c0i / 2; r < c1i / 2; ++r)
+            if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
+          if (c1i < HN) BMPC_FENCE();
         }
-        bcast_sync();
-        if (hf == 0) {
-          Vr[u] = is0 ? -q00 : (is1 ? -q01 : t0);
-          Vr[u + 1] = is0 ? -q01 : (is1 ? -q11 : t1);
-        }
+        if (hf == 0) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
       }
       {                                        // rotate left by U across the pair
-        float tmp[U];
+        f2 tmp[U / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) tmp[u] = pair_swap(Vr[u]);
+        for (int u = 0; u < U / 2; ++u) tmp[u] = pair_swap(Vr[u]);
 #pragma unroll
-        for (int r = 0; r + U < HN; ++r) Vr[r] = Vr[r + U];
+        for (int r = 0; r + U / 2 < HN / 2; ++r) Vr[r] = Vr[r + U / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) Vr[HN - U + u] = tmp[u];
+        for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
       }
       pos = posn;
       ws = wsn;
@@ -1049,8 +1024,7 @@ solve_kernel(const DevParams P, const int B,
     // finite (a failed solve) is ignored.
     int js = j + warm.shift;
     js = js > H - 1 ? H - 1 : js;
-    const int rs = 6 * js + c;                  // the lane that owned this variable `shift` steps later
-    const double* src = warm.buf + ((size_t)inst * NT + (32 * (rs >> 4) + 16 * f + (rs & 15))) * 6;
+    const double* src = warm.buf + ((size_t)inst * NT + (2 * (6 * js + c) + f)) * 6;
     double wv[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) wv[k] = src[k];
@@ -1080,17 +1054,6 @@ solve_kernel(const DevParams P, const int B,
       need_factor = false;
     }
     if (dbg.prof) t_last = clock64();
-    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
-    const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
-    float ginc = 0.f;
-    {
-    // The lane's indices are re-materialised (opaque copies) in every iteration: some forty LDS addresses
-    // derived from them are loop invariant, and hoisted out of the loop each of them holds a register across
-    // the factorisation and the iterations -- the registers that decide how many waves share a SIMD.
-    const int j_q = j, c_q = c, f_q = f, hf_q = hf, row_q = row, ln_q = ln;
-    {
-    int j = j_q, c = c_q, f = f_q, hf = hf_q, row = row_q, ln = ln_q;
-    BMPC_OPAQUE(j); BMPC_OPAQUE(c); BMPC_OPAQUE(f); BMPC_OPAQUE(hf); BMPC_OPAQUE(row); BMPC_OPAQUE(ln);
     // --- P0: row residuals w = y + rho (A x - z); publish them and the gradient
     RT wb = 0;
     if (valid) {
@@ -1173,20 +1136,23 @@ solve_kernel(const DevParams P, const int B,
     }
     __syncthreads();
     BMPC_STAMP(3)
-    // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S).  beta reaches the
-    // FMAs by DPP broadcast from the lane of the row of 16 that fetched it: NR loads per lane instead of HN.
+    // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S)
     float gown;
     {
-      float RB4[NR];
+      f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < NR; ++k) RB4[k] = sm.u.itv.beta[hf * HNP + 16 * k + ln];
-      BMPC_SCHED_BARRIER();
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      BMPC_BCAST_PUBLISH_ALL(RB4, RB4, NR);
-      bcast_sync();
-      BcastDot<0, HN, HN, NR>::run(acc, Vr, RB4);
-      bcast_sync();
-      float part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      for (int q = 0; q < HN; q += 4) {
+        if (q + 4 <= HN) {
+          const float4 bq = *reinterpret_cast<const float4*>(&sm.u.itv.beta[hf * HNP + q]);
+          a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+          a1 = __builtin_elementwise_fma(Vr[q / 2 + 1], f2{bq.z, bq.w}, a1);
+        } else {
+          const float2 bq = *reinterpret_cast<const float2*>(&sm.u.itv.beta[hf * HNP + q]);
+          a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+        }
+        if (HN > 32 && q % 16 == 12) BMPC_FENCE();
+      }
+      float part = (a0.x + a0.y) + (a1.x + a1.y);
       part += pair_swap(part);
       gown = -part * dsc;
     }
@@ -1198,6 +1164,9 @@ solve_kernel(const DevParams P, const int B,
     __syncthreads();
     BMPC_STAMP(4)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
+    const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
+    float ginc = 0.f;
     if (valid) {
       float gm[6];
 #pragma unroll
@@ -1276,8 +1245,6 @@ solve_kernel(const DevParams P, const int B,
         // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
         nx = (st_x == st_x) ? fabsf((float)st_x) : __builtin_inff();
       }
-    }
-    }
     }
     ginc += pair_swap(ginc);
     gbl -= alpha * (RT)ginc;

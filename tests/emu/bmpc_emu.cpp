@@ -68,16 +68,10 @@ static inline float rsq_approx(float x) { return 1.0f / std::sqrt(x); }
 static inline int pair_swap_i(int v) {
   g_swap[threadIdx.x] = v;
   __syncthreads();
-  const int r = g_swap[threadIdx.x ^ 16];
+  const int r = g_swap[threadIdx.x ^ 1];
   __syncthreads();
   return r;
 }
-// DPP row_newbcast: the operand registers are published once (plane K), then read by the 16 lanes of the row
-static float g_bc[16][1024];
-template <int K, int N>
-static inline void fmac_bcast(float& acc, float, float mul) { acc = std::fma(g_bc[K][(threadIdx.x & ~15) + N], mul, acc); }
-static inline void bcast_sync() { __syncthreads(); }
-#define BMPC_BCAST_PUBLISH_ALL(RA, RB, NR) do { for (int k_ = 0; k_ < (NR); ++k_) { g_bc[k_][threadIdx.x] = (RA)[k_]; g_bc[(NR) + k_][threadIdx.x] = (RB)[k_]; } } while (0)
 static inline unsigned wave_umax(unsigned v) {          // maximum over the lane's wave (64 consecutive lanes)
   g_red[threadIdx.x] = v;
   __syncthreads();

@@ -39,7 +39,9 @@ def test_no_spills_and_two_waves_per_simd(tmp_path):
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_no_dpp_hazard_behind_inline_asm(tmp_path):
-    """The broadcast FMAs are inline-asm `v_fmac_f32_dpp`; the compiler's hazard recogniser does not look inside
+    """Guard for inline-asm DPP instructions (the DPP-broadcast sweep variant of DESIGN.md section 9 used
+    `v_fmac_f32_dpp`; the shipped kernel has none, the compiler's own DPP moves are hazard-checked by the
+    compiler).  The compiler's hazard recogniser does not look inside
     inline asm, so nothing inserts the two wait states a DPP read needs after a VALU write of the same register.
     The kernels feed them from LDS loads only; this test scans the generated ISA to make sure no vector
     instruction writes a DPP source register within the two instructions before its DPP read."""
@@ -69,4 +71,4 @@ def test_no_dpp_hazard_behind_inline_asm(tmp_path):
             src = int(re.findall(r"v(\d+)", ln)[1])
             for k in (1, 2):
                 assert src not in written(lines[i - k]), (lines[i - k], ln)
-    assert n > 300          # the sweep and the V mat-vec of three horizons
+    print("inline-asm DPP instructions checked:", n)      # none in the shipped variant (the broadcast sweep is not kept)
