@@ -394,7 +394,7 @@ def run_rank(args):
                          "frac": ach / PEAK_FP32_TFLOPS,
                          "achieved_minimal": ach_min, "frac_minimal": ach_min / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": f"bmpc::solve_kernel<{h},double>", "kernel_ms": kernel_ms,
+                         "kernel": f"bmpc::solve_kernel<{h}>", "kernel_ms": kernel_ms,
                          "flops_per_solve": fl_s, "flops_per_solve_minimal": fl_r, "flops_parts_minimal": parts,
                          "note": "compute-bound on the packed-f32 vector pipe (no MFMA in this kernel: the f32 matrix "
                                  "rate of CDNA4 equals the vector rate); `achieved` uses SURVEY 8(d)'s dense "
