@@ -48,7 +48,7 @@ class CParams(C.Structure):
         ("rho_hi_f", C.c_double), ("rho_hi_m", C.c_double), ("kappa", C.c_double), ("alpha", C.c_double),
         ("eps_pri", C.c_double), ("eps_dua", C.c_double),
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
-        ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("reserved", C.c_int32),
+        ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("warm_adapt_start", C.c_int32),
         ("kp", C.c_double * 9), ("kd", C.c_double * 9), ("swingHeight", C.c_double), ("hip_offset", C.c_double * 3),
     ]
 

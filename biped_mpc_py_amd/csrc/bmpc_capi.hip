@@ -127,7 +127,7 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
              hipStream_t st) {
   constexpr int NT = bmpc::Dims<H>::NT;
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f};
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0};
   if (hd->warm_on && !dbg.assemble_only) {
     const size_t need = (size_t)B * NT * 6;
     if (need > hd->warm.n) hd->warm_valid = false;          // growing the buffer loses the stored state
@@ -137,6 +137,7 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
     warm.store = 1;
     warm.shift = hd->warm_shift;
     warm.theta = hd->warm_theta;
+    warm.adapt_start = hd->params.warm_adapt_start;
   }
   hipLaunchKernelGGL((bmpc::solve_kernel<H>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
                      phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
@@ -202,6 +203,7 @@ int bmpc_default_params(bmpc_params* p, int h) {
   p->rho = 0.03; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 20.0;
   p->alpha = 1.6; p->eps_pri = 1e-7; p->eps_dua = 1e-7;
   p->max_iter = 400; p->check_every = 5; p->adapt_start = 10; p->adapt_every = 10; p->max_refactor = 24;
+  p->warm_adapt_start = 5;                                            // (tools/warm_sweep.py)
   p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
   p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31
   p->swingHeight = 0.1;                                               // REF:32

@@ -84,6 +84,7 @@ struct WarmArgs {
   int load, store;           // start from buf / leave the final state in buf
   int shift;                 // the stored horizon is advanced by this many steps on load (0: same schedule phase)
   float theta;               // penalties restart at rho0 (rho_stored / rho0)^theta: 1 keeps them, 0 forgets them
+  int adapt_start;           // first penalty re-classification of a warm-started solve (<= 0: as for a cold one)
 };
 
 template <int H>
@@ -1044,6 +1045,7 @@ solve_kernel(const DevParams P, const int B,
       irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
     }
     refresh();                                 // axg, gbl of the loaded x (barriers inside: all lanes)
+    if (warm.adapt_start > 0 && P.adapt_every > 0) next_adapt = warm.adapt_start;
   }
 
 #pragma unroll 1

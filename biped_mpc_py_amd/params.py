@@ -45,7 +45,7 @@ class Biped:
 
 # solver knobs (bmpc_default_params): overridable through solver_options
 SOLVER_FIELDS = ("rho", "rho_eq_scale", "rho_lo", "rho_hi_f", "rho_hi_m", "kappa", "alpha", "eps_pri", "eps_dua",
-                 "max_iter", "check_every", "adapt_start", "adapt_every", "max_refactor")
+                 "max_iter", "check_every", "adapt_start", "adapt_every", "max_refactor", "warm_adapt_start")
 
 
 def pack_params(mpc=None, biped=None, half=None, solver_options=None):

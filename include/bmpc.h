@@ -84,7 +84,7 @@ typedef struct bmpc_params {
   int32_t adapt_start;       /* first penalty re-classification */
   int32_t adapt_every;       /* re-classification period (0 = never) */
   int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached) */
-  int32_t reserved;
+  int32_t warm_adapt_start;  /* first re-classification of a warm-started solve (bmpc_set_warm_start); 0 = adapt_start */
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
   double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
   double swingHeight;        /* REF:32 */

@@ -148,7 +148,7 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.rho_hi_f = (float)p->rho_hi_f; d.rho_hi_m = (float)p->rho_hi_m;
   d.eps_pri = (float)p->eps_pri; d.eps_dua = (float)p->eps_dua; d.kappa = (float)p->kappa;
   bmpc::DebugOut dbg = {dbg_x_ref, dbg_foot_ref, dbg_Gt, dbg_qt, nullptr, assemble_only};
-  bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta};
+  bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta, p->warm_adapt_start};
   switch (p->h) {
     case 10: run_h<10>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
     case 16: run_h<16>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;

@@ -588,5 +588,5 @@ def test_closed_loop_rollout_and_warm_start(gait):
         assert np.allclose(t.cpu().numpy(), t0 + K * mpc.dt)
         s.close()
     assert np.array_equal(out[True][0], out[False][0])             # the first period starts cold either way
-    # measured: 0.69x in double support, 0.93x while the contact schedule advances every period
-    assert out[True][1:].mean() < (0.8 if gait == "standing" else 1.0) * out[False][1:].mean()
+    # measured: 0.60x in double support, 0.84x while the contact schedule advances every period
+    assert out[True][1:].mean() < (0.7 if gait == "standing" else 0.95) * out[False][1:].mean()
