@@ -1022,7 +1022,7 @@ solve_kernel(const DevParams P, const int B,
     // Start from the previous solve of this batch slot: iterate and multipliers of the lane that owned the same
     // variable `shift` steps later (the last step repeats), projected onto the new bounds; penalties pulled back
     // towards rho0 so that a row whose activity changed needs one or two moves, not four.  A state that is not
-    // finite (a failed solve) is ignored.
+    // finite (a failed solve) is ignored as a whole.
     int js = j + warm.shift;
     js = js > H - 1 ? H - 1 : js;
     const double* src = warm.buf + ((size_t)inst * NT + (2 * (6 * js + c) + f)) * 6;
@@ -1033,6 +1033,7 @@ solve_kernel(const DevParams P, const int B,
     bool ok = pb0 > 0.f && pg0 > 0.f && pb0 < 3.0e38f && pg0 < 3.0e38f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) ok = ok && (fabs(wv[k]) < 1.0e300);
+    ok = __syncthreads_or(ok ? 0 : 1) == 0;    // all of the instance's state or none of it
     if (ok) {
       xo = wv[0];
       zb = fmin(fmax(wv[1], (RT)lb), (RT)ub);
@@ -1045,7 +1046,7 @@ solve_kernel(const DevParams P, const int B,
       irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
     }
     refresh();                                 // axg, gbl of the loaded x (barriers inside: all lanes)
-    if (warm.adapt_start > 0 && P.adapt_every > 0) next_adapt = warm.adapt_start;
+    if (ok && warm.adapt_start > 0 && P.adapt_every > 0) next_adapt = warm.adapt_start;
   }
 
 #pragma unroll 1
