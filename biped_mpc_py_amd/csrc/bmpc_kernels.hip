@@ -123,7 +123,7 @@ struct alignas(16) FacScratch {
   double M0[H][6][6];        // D0 -> Ka^-1 D0 W_0^-1
   double M1[H][6][6];        // D1 -> Ka^-1
   double M2[H][6][6];        // B = T' D1 T -> L_0
-  double ex[H][6];           // pivot-column exchange for the cooperative 6x6 sweep
+  double Ka[H][6][6];        // Ka = D0 + B, read whole by every lane of the step
 };
 template <int H>
 struct IterScratch {
@@ -237,36 +237,51 @@ __device__ __forceinline__ void row_times_mat6(const double (&w)[6], const doubl
   }
 }
 
-// Cooperative symmetric sweep of one 6x6 SPD matrix per step: the lanes with `on` (one per row (j, c)) hold
-// row c.  On exit the rows hold the INVERSE.  All threads of the workgroup must call (barriers inside).
-template <int H>
-__device__ __forceinline__ void sweep6(double (&m)[6], Smem<H>& sm, bool on, int j, int c) {
+// Row c of the inverse of a 6x6 SPD matrix in LDS, computed by the calling lane alone (LDL' of the lower
+// triangle, then L D L' x = e_c): ~130 f64 operations and no exchange, where a cooperative sweep over the six
+// lanes of the step costs twelve barriers -- the factorisation is latency-bound, not flop-bound.  The six lanes
+// of a step repeat the same LDL'.  Reciprocals by v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ void inv6_row(const double (*K)[6], int c, double (&x)[6]) {
+  double a[6][6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    if (on) sm.u.fac.ex[j][c] = m[k];
-    __syncthreads();
-    if (on) {
-      double col[6];
+  for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int b = 0; b < 6; ++b) col[b] = sm.u.fac.ex[j][b];
-      // reciprocal by v_rcp_f64 + two Newton steps (a correctly rounded IEEE division is ~40 dependent instructions)
-      double pinv = rcp_approx(col[k]);
-      pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
-      pinv = fma(fma(-col[k], pinv, 1.0), pinv, pinv);
-      const bool isp = (c == k);
-      const double t = isp ? -pinv : m[k] * pinv;
+    for (int k = 0; k <= i; ++k) a[i][k] = K[i][k];
+  BMPC_SCHED_BARRIER();
+  double dinv[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        if (b == k) continue;
-        m[b] = isp ? col[b] * pinv : fma(-t, col[b], m[b]);
-      }
-      m[k] = t;            // pivot lane: -1/p ; others: a_ik / p
+  for (int jj = 0; jj < 6; ++jj) {
+    double d = a[jj][jj];
+#pragma unroll
+    for (int k = 0; k < jj; ++k) d = fma(-a[jj][k] * a[jj][k], a[k][k], d);      // a[k][k] holds d_k, a[i][k] holds l_ik
+    double r = rcp_approx(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    dinv[jj] = r;
+    a[jj][jj] = d;
+#pragma unroll
+    for (int i = jj + 1; i < 6; ++i) {
+      double v = a[i][jj];
+#pragma unroll
+      for (int k = 0; k < jj; ++k) v = fma(-a[i][k] * a[jj][k], a[k][k], v);
+      a[i][jj] = v * r;
     }
-    __syncthreads();
   }
-  // swept matrix = -A^-1
+  double y[6];
 #pragma unroll
-  for (int b = 0; b < 6; ++b) m[b] = -m[b];
+  for (int i = 0; i < 6; ++i) {                  // L y = e_c
+    double v = (c == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = fma(-a[i][k], y[k], v);
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {                 // L' x = D^-1 y
+    double v = y[i] * dinv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v = fma(-a[k][i], x[k], v);
+    x[i] = v;
+  }
 }
 
 template <typename T>
@@ -684,7 +699,7 @@ solve_kernel(const DevParams P, const int B,
     // (B, Ka^-1, L_0, F), lane 1 the D0 chain (Ka^-1 D0 W_0^-1, L_1, T Ka^-1).
     const bool on0 = valid && hf == 0, on1 = valid && hf == 1;
     double urow[6];                             // row c of U = W_0^-T D0
-    double ka[6];                               // row c of Ka -> Ka^-1
+    double ka[6];                               // row c of Ka^-1
     if (on0) {
       double yq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       row_times_mat6(Tcol, sm.u.fac.M1[j], yq);
@@ -695,7 +710,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
         for (int q = 0; q < 6; ++q) s = fma(yq[q], Tm[q][b], s);
         brow[b] = s;
-        ka[b] = m3[b] + s;
+        sm.u.fac.Ka[j][c][b] = m3[b] + s;
       }
       // U = W_0^-T D0 = [[0, I], [I, [r_0]x]] D0: rows 0..2 are rows 3..5 of D0, row 3+a is row a + ([r_0]x D0[3:6])_a
       double wti[6];                            // row c of W_0^-T
@@ -725,23 +740,16 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
-    sweep6<H>(ka, sm, on0, j, c);               // -> Ka^-1 (barriers inside: the M1 reads above are done)
+    __syncthreads();                          // Ka, B published; D1 consumed
+    inv6_row(sm.u.fac.Ka[j], co, ka);           // both lanes of the row, each for itself: no exchange
     if (on0) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.u.fac.M1[j][c][b] = ka[b];
+      for (int b = 0; b < 6; ++b) sm.u.fac.M1[j][c][b] = ka[b];     // the whole Ka^-1 is needed for T Ka^-1 below
     }
-    __syncthreads();                          // Ka^-1 published
     double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
-    if (on1) {
-#pragma unroll
-      for (int b = 0; b < 6; b += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(&sm.u.fac.M1[j][c][b]);
-        ka[b] = v.x; ka[b + 1] = v.y;
-      }
-    }
     if (on0) row_times_mat6(ka, sm.u.fac.M2[j], xk);
     if (on1) row_times_mat6(ka, sm.u.fac.M0[j], xk);
-    __syncthreads();                          // B, D0 consumed
+    __syncthreads();                          // B, D0 consumed; Ka^-1 published
     if (valid) {
       const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
       // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0]
