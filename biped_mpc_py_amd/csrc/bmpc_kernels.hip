@@ -53,13 +53,6 @@ __device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_upda
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 __device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
-#ifndef BMPC_EMU
-// value of lane SEL[q] of the caller's quad (4 consecutive lanes), q = own position: DPP quad_perm
-template <int S0, int S1, int S2, int S3>
-__device__ __forceinline__ float quad_read(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xf, 0xf, false));
-}
-#endif
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
 __device__ __forceinline__ double pair_swap(double v) {
   const int lo = pair_swap_i(__double2loint(v)), hi = pair_swap_i(__double2hiint(v));
@@ -114,19 +107,12 @@ struct Dims {
   // the two addresses of a wave's ds_read_b128 (even lanes: half 0, odd lanes: half 1) never share a bank.
   static constexpr int HNP = ((HN + 3) / 4) * 4;
   static constexpr int VL = 2 * HNP;
-  // The dense matrix V lives in 2 x QN tiles: the four lanes of a quad hold rows 2 i, 2 i + 1 and a quarter of the
-  // columns each.  A vector over the wrench rows that the quarters read sits in LDS as four 16-byte aligned
-  // quarters of QNP floats (entry i at qslot(i)).
-  static constexpr int QN = NW / 4;
-  static constexpr int QNP = ((QN + 3) / 4) * 4;
-  static constexpr int PVS = 4 * QNP + NT;               // one published pivot column + one dump slot per lane
+  static constexpr int PVS = ((VL + NW + 3) / 4) * 4;    // one published pivot column: two-half vector + one dump slot per row
   static_assert(HNP % 64 >= 4 && HNP % 64 <= 60, "halves of a two-half vector would collide on LDS banks");
   // Gt row half: 3 component groups x HH steps, padded to whole float4s
   static constexpr int GH = ((3 * HH + 3) / 4) * 4;
   static constexpr int GS = (GH % 16 == 0 && GH % 64 != 16 && GH % 64 != 48) ? GH + 4 : GH;   // stride of the 4 gamma copies
 };
-template <int H>
-__device__ __forceinline__ constexpr int qslot(int i) { return (i / Dims<H>::QN) * Dims<H>::QNP + i % Dims<H>::QN; }
 template <int H>
 __device__ __forceinline__ constexpr int slot(int i) { return i < Dims<H>::HN ? i : i - Dims<H>::HN + Dims<H>::HNP; }
 
@@ -146,7 +132,7 @@ struct IterScratch {
   alignas(16) RT bwT[6][H];  // net wrench of x, component-major: a lane reads its inputs of Gt contiguously
   RT gb[NW];                 // wrench-space gradient Gt b + qt
   alignas(16) float r32[H][2][6];   // KKT residual, control space
-  alignas(16) float beta[4 * Dims<H>::QNP];   // d .* L' r, four-quarter layout
+  alignas(16) float beta[Dims<H>::VL];   // d .* L' r, two-half layout
   alignas(16) float gam[NW];
   // gamma again for the gradient increment: per (component group = torque / force, column half) the 3 HH
   // values a lane multiplies with its Gt row half, contiguous, zero padded to GH
@@ -361,7 +347,7 @@ solve_kernel(const DevParams P, const int B,
   // to be predicated (every `if (lane is real)` would be an exec-mask branch, and the code sinking across such
   // branches is what blew up the sweep's register pressure); only their global stores are suppressed.
   const bool real = (l >> 1) < NW;
-  const int row = real ? (l >> 1) : NW - 2 + ((l >> 1) & 1);   // (a clone quad repeats the last quad: rows NW - 2, NW - 1)
+  const int row = real ? (l >> 1) : NW - 1;
   constexpr bool valid = true;
   const int j = row / 6;
   const int c = row % 6;
@@ -637,9 +623,7 @@ solve_kernel(const DevParams P, const int B,
   RT irvb = (RT)1 / (RT)rvb, irvg = (RT)1 / (RT)rvg;  // reciprocals (refreshed with the penalties)
   // Half a row of -(S (Gt + F) S)^-1 after the sweep (S = Jacobi scaling to unit diagonal), as float pairs:
   // the sweep and the V mat-vec run on the packed-f32 pipe (v_pk_fma_f32: two f32 per lane and instruction)
-  constexpr int QN = Dims<H>::QN, QNP = Dims<H>::QNP;
-  const int q4 = l & 3;                       // position in the quad = column quarter of the tile this lane holds
-  f2 V2[QN];                                  // tile of -S V S: {V[2 i][s], V[2 i + 1][s]} for the QN columns of quarter q4
+  f2 Vr[HN / 2];
   float dsc = 1.f;                            // S[row]
 #define VROW(q) Vr[(q) >> 1][(q) & 1]
 
@@ -823,7 +807,6 @@ solve_kernel(const DevParams P, const int B,
     if (dbg.prof) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
     // K' row half = Gt row half + F row on the own step, scaled to unit diagonal (S K' S, S = diag(K')^-1/2:
     // every pivot of the sweep is then <= 1, which the pivot-row update below relies on).
-    f2 Vr[HN / 2];                              // the dense row half, only while it is being built
     float fv[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
@@ -869,110 +852,98 @@ solve_kernel(const DevParams P, const int B,
         }
       }
     }
-    // Row halves -> tiles.  The quad of lanes 4 i .. 4 i + 3 holds rows 2 i (lanes 0, 1: column halves 0, 1) and
-    // 2 i + 1 (lanes 2, 3); lane q of it takes both rows' entries of column quarter q, two rows per register
-    // pair: every fetched pivot-row entry then feeds TWO rows, which halves the LDS traffic of the sweep and of
-    // the mat-vec (the broadcast fetch of operands is what loads the LDS, section 6 of DESIGN.md).
-#pragma unroll
-    for (int sq = 0; sq < QN; ++sq) {
-      const float a_lo = quad_read<0, 0, 1, 1>(VROW(sq)), a_hi = quad_read<0, 0, 1, 1>(VROW(QN + sq));
-      const float b_lo = quad_read<2, 2, 3, 3>(VROW(sq)), b_hi = quad_read<2, 2, 3, 3>(VROW(QN + sq));
-      V2[sq] = (q4 & 1) ? f2{a_hi, b_hi} : f2{a_lo, b_lo};
-    }
-    // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of quarter q
-    // holds column (k0 + q QN + i) mod NW, so the pivot columns k, k + 1 are always two static registers of the
-    // quarter-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the quarter-0 lanes publish their entries of the pivot
-    // columns (= pivot rows, by symmetry), every lane fetches the 2 QN entries of its quarter, forms T[r, :] =
-    // V[r, S] P^-1 for its two rows and updates with TWO packed FMAs per register pair (one per pivot, the two
-    // rows in the two halves):  row -= T[r, 0] row_k + T[r, 1] row_k+1; the pivot rows themselves use T[r, :] =
-    // e_r - P^-1[r, :], which turns them into P^-1 V[S, :] (exact up to rounding because the scaled pivots are
-    // <= 1; no second multiply, and a row is never rebuilt from a column -- measured asymmetry 2e-7, same accuracy
-    // as the re-symmetrising form).  The entries in the columns S become T (V[r, S] P^-1) and, in the pivot
-    // block, -P^-1.  Two pivots per barrier and LDS round trip; the update of the NEXT pair of pivot columns is
-    // done first and published at once (into the other buffer), so that its round trip overlaps with the rest of
-    // this step's updates.
+    // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of half hf
+    // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always one static register pair
+    // of the half-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the half-0 lanes publish their two entries of the
+    // pivot columns (= pivot rows, by symmetry), every lane fetches the 2 HN entries of its half, forms its
+    // T[r, :] = V[r, S] P^-1 and updates with TWO packed FMAs per register pair:  row -= T[r, 0] row_k +
+    // T[r, 1] row_k+1; the pivot rows themselves use T[r, :] = e_r - P^-1[r, :], which turns them into
+    // P^-1 V[S, :] (exact up to rounding because the scaled pivots are <= 1; no second multiply, and a row is
+    // never rebuilt from a column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
+    // The entries in the columns S become T (V[r, S] P^-1) and, in the pivot block, -P^-1.
+    // Two pivots per barrier and LDS round trip instead of one; the update of the NEXT pair of pivot columns
+    // is done first and published at once (into the other buffer), so that its round trip overlaps with the
+    // rest of this step's updates.
     constexpr int U = 6;
-    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= QN, "sweep group must divide 6H and be even");
-    constexpr int PVS = Dims<H>::PVS;            // floats per published column (four-quarter layout + dump slots)
-    const int r0 = row & ~1;                     // the first of this lane's two rows
-    int pos = r0;                                // its rotated index (group 0); the second row's is pos + 1
-    int w0 = q4 == 0 ? qslot<H>(pos) : 4 * QNP + l, w1 = q4 == 0 ? qslot<H>(pos + 1) : 4 * QNP + l;
-    sm.piv[0][w0] = V2[0].x; sm.piv[0][w1] = V2[0].y;
-    sm.piv[0][PVS + w0] = V2[1].x; sm.piv[0][PVS + w1] = V2[1].y;
+    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
+    constexpr int PVS = Dims<H>::PVS;            // floats per published column (two-half layout + dump slots)
+    int pos = row;                              // rotated index of the own row (group 0)
+    int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
+    sm.piv[0][ws] = Vr[0].x;
+    sm.piv[0][PVS + ws] = Vr[0].y;
     int par = 0;                                // buffer of the current step (a group has an odd number of steps)
 #pragma unroll 1
     for (int k0 = 0; k0 < NW; k0 += U) {
-      const int ps0 = qslot<H>(pos), ps1 = qslot<H>(pos + 1);
+      const int ps = slot<H>(pos);
       int posn = pos - U;                       // ... and in the next group
       posn += (posn < 0) ? NW : 0;
-      const int w0n = q4 == 0 ? qslot<H>(posn) : 4 * QNP + l, w1n = q4 == 0 ? qslot<H>(posn + 1) : 4 * QNP + l;
+      const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
 #pragma unroll
       for (int u = 0; u < U; u += 2) {
         const float* bA = sm.piv[par];                   // column k
         const float* bB = bA + PVS;                      // column k + 1
         float* nA = sm.piv[par ^ 1];
         par ^= 1;
-        const int un = u + 2;                            // registers of the next pivot columns (u + 2 == U: first of the next group)
+        const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
         __syncthreads();
         const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
         const float p11 = bB[u + 1];
-        const float cA0 = bA[ps0], cA1 = bA[ps1], cB0 = bB[ps0], cB1 = bB[ps1];   // V[r0][k], V[r0 + 1][k], V[r0][k + 1], V[r0 + 1][k + 1]
+        const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
         BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
         const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
         const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
-        const int k = k0 + u;
-        const bool x0 = (r0 == k), x1 = (r0 == k + 1), y0 = (r0 + 1 == k), y1 = (r0 + 1 == k + 1);
-        float t0x = cA0 * q00 + cB0 * q01, t1x = cA0 * q01 + cB0 * q11;
-        float t0y = cA1 * q00 + cB1 * q01, t1y = cA1 * q01 + cB1 * q11;
-        t0x = x0 ? 1.f - q00 : (x1 ? -q01 : t0x);  t1x = x0 ? -q01 : (x1 ? 1.f - q11 : t1x);
-        t0y = y0 ? 1.f - q00 : (y1 ? -q01 : t0y);  t1y = y0 ? -q01 : (y1 ? 1.f - q11 : t1y);
-        const f2 m0 = {-t0x, -t0y}, m1 = {-t1x, -t1y};
+        const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
+        float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
+        t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
+        t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
+        const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
         // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the
         // next pivot columns first
-        constexpr int CH = QNP <= 16 ? QNP : 16;
+        constexpr int CH = HN <= 32 ? HN : 16;
+        static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
 #pragma unroll
-        for (int c0i = 0; c0i < QN; c0i += CH) {
-          const int c1i = c0i + CH < QN ? c0i + CH : QN;
-          float pa[CH], pb[CH];
+        for (int c0i = 0; c0i < HN; c0i += CH) {
+          const int c1i = c0i + CH < HN ? c0i + CH : HN;
+          f2 pa[CH / 2], pb[CH / 2];
 #pragma unroll
-          for (int qq = 0; qq < CH; qq += 4) {
-            if (c0i + qq < QN) {
-              const float4 a4 = *reinterpret_cast<const float4*>(&bA[q4 * QNP + c0i + qq]);
-              const float4 b4 = *reinterpret_cast<const float4*>(&bB[q4 * QNP + c0i + qq]);
-              pa[qq] = a4.x; pa[qq + 1] = a4.y; pa[qq + 2] = a4.z; pa[qq + 3] = a4.w;
-              pb[qq] = b4.x; pb[qq + 1] = b4.y; pb[qq + 2] = b4.z; pb[qq + 3] = b4.w;
+          for (int q = c0i; q < c1i; q += 4) {
+            if (q + 4 <= c1i) {
+              const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
+              const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
+              pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
+            } else {
+              const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
+              const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a2.x, a2.y};
+              pb[(q - c0i) / 2] = f2{b2.x, b2.y};
             }
           }
           if (c0i == 0) {
-            static_assert(U + 2 <= CH, "the next pivot pair lies in the first chunk");
-            V2[un] = __builtin_elementwise_fma(m1, f2{pb[un], pb[un]}, __builtin_elementwise_fma(m0, f2{pa[un], pa[un]}, V2[un]));
-            V2[un + 1] = __builtin_elementwise_fma(m1, f2{pb[un + 1], pb[un + 1]}, __builtin_elementwise_fma(m0, f2{pa[un + 1], pa[un + 1]}, V2[un + 1]));
-            const int wa = u + 2 < U ? w0 : w0n, wb = u + 2 < U ? w1 : w1n;   // (after the very last step: columns nobody reads)
-            nA[wa] = V2[un].x; nA[wb] = V2[un].y;
-            nA[PVS + wa] = V2[un + 1].x; nA[PVS + wb] = V2[un + 1].y;
+            static_assert(U / 2 + 1 <= CH / 2, "the next pivot pair lies in the first chunk");
+            Vr[un] = __builtin_elementwise_fma(m1, pb[un], __builtin_elementwise_fma(m0, pa[un], Vr[un]));
+            const int wn = u + 2 < U ? ws : wsn;         // (after the very last step: columns nobody reads)
+            nA[wn] = Vr[un].x;
+            nA[PVS + wn] = Vr[un].y;
           }
 #pragma unroll
-          for (int r = c0i; r < c1i; ++r)
-            if (r != un && r != un + 1)
-              V2[r] = __builtin_elementwise_fma(m1, f2{pb[r - c0i], pb[r - c0i]}, __builtin_elementwise_fma(m0, f2{pa[r - c0i], pa[r - c0i]}, V2[r]));
-          if (c1i < QN) BMPC_FENCE();
+          for (int r = c0i / 2; r < c1i / 2; ++r)
+            if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
+          if (c1i < HN) BMPC_FENCE();
         }
-        if (q4 == 0) {
-          V2[u] = f2{x0 ? -q00 : (x1 ? -q01 : t0x), y0 ? -q00 : (y1 ? -q01 : t0y)};
-          V2[u + 1] = f2{x0 ? -q01 : (x1 ? -q11 : t1x), y0 ? -q01 : (y1 ? -q11 : t1y)};
-        }
+        if (hf == 0) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
       }
-      {                                        // rotate left by U across the quad: quarter q takes over quarter q + 1's first U columns
-        f2 tmp[U];
+      {                                        // rotate left by U across the pair
+        f2 tmp[U / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) tmp[u] = f2{quad_read<1, 2, 3, 0>(V2[u].x), quad_read<1, 2, 3, 0>(V2[u].y)};
+        for (int u = 0; u < U / 2; ++u) tmp[u] = pair_swap(Vr[u]);
 #pragma unroll
-        for (int r = 0; r + U < QN; ++r) V2[r] = V2[r + U];
+        for (int r = 0; r + U / 2 < HN / 2; ++r) Vr[r] = Vr[r + U / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) V2[QN - U + u] = tmp[u];
+        for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
       }
       pos = posn;
-      w0 = w0n; w1 = w1n;
+      ws = wsn;
     }
     if (dbg.prof) t_sweep += clock64() - t_mark;
   };
@@ -1157,7 +1128,7 @@ solve_kernel(const DevParams P, const int B,
       for (int i = 0; i < 6; ++i) bsum = fmaf(lcol[i], f == 0 ? rj[0][i] : rj[1][i], bsum);
     }
     bsum += pair_swap(bsum);
-    sm.u.itv.beta[qslot<H>(row)] = bsum * dsc;  // both lanes of the pair: same value (a + b == b + a)
+    sm.u.itv.beta[slot<H>(row)] = bsum * dsc;   // both lanes of the pair: same value (a + b == b + a)
     // the part of the step that does not need gamma (off the critical path, before the barrier):
     // t = N' r = r_0 - T' r_1 ;  null-space part of d: foot 0 gets Ka^-1 t, foot 1 gets -(T Ka^-1) t
     f2 ddk = {0.f, 0.f};
@@ -1176,23 +1147,25 @@ solve_kernel(const DevParams P, const int B,
     }
     __syncthreads();
     BMPC_STAMP(3)
-    // --- P4: gamma = V beta: both rows of the tile against the own column quarter, summed over the quad   (V2 holds -S V S)
+    // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S)
     float gown;
     {
       f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-      for (int qq = 0; qq < QN; qq += 4) {
-        const float4 bq = *reinterpret_cast<const float4*>(&sm.u.itv.beta[q4 * QNP + qq]);
-        a0 = __builtin_elementwise_fma(V2[qq], f2{bq.x, bq.x}, a0);
-        if (qq + 1 < QN) a1 = __builtin_elementwise_fma(V2[qq + 1 < QN ? qq + 1 : 0], f2{bq.y, bq.y}, a1);
-        if (qq + 2 < QN) a0 = __builtin_elementwise_fma(V2[qq + 2 < QN ? qq + 2 : 0], f2{bq.z, bq.z}, a0);
-        if (qq + 3 < QN) a1 = __builtin_elementwise_fma(V2[qq + 3 < QN ? qq + 3 : 0], f2{bq.w, bq.w}, a1);
-        if (QN > 16 && qq % 16 == 12) BMPC_FENCE();
+      for (int q = 0; q < HN; q += 4) {
+        if (q + 4 <= HN) {
+          const float4 bq = *reinterpret_cast<const float4*>(&sm.u.itv.beta[hf * HNP + q]);
+          a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+          a1 = __builtin_elementwise_fma(Vr[q / 2 + 1], f2{bq.z, bq.w}, a1);
+        } else {
+          const float2 bq = *reinterpret_cast<const float2*>(&sm.u.itv.beta[hf * HNP + q]);
+          a0 = __builtin_elementwise_fma(Vr[q / 2], f2{bq.x, bq.y}, a0);
+        }
+        if (HN > 32 && q % 16 == 12) BMPC_FENCE();
       }
-      f2 part = a0 + a1;                        // {row 2 i, row 2 i + 1} over this quarter
-      part += f2{quad_read<1, 0, 3, 2>(part.x), quad_read<1, 0, 3, 2>(part.y)};
-      part += f2{quad_read<2, 3, 0, 1>(part.x), quad_read<2, 3, 0, 1>(part.y)};
-      gown = -((row & 1) ? part.y : part.x) * dsc;
+      float part = (a0.x + a0.y) + (a1.x + a1.y);
+      part += pair_swap(part);
+      gown = -part * dsc;
     }
     {                                          // lane 0 of the pair: step-major copy, lane 1: the copy for the gradient increment
       float* gdst = hf == 0 ? &sm.u.itv.gam[row]

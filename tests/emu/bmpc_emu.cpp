@@ -72,15 +72,6 @@ static inline int pair_swap_i(int v) {
   __syncthreads();
   return r;
 }
-template <int S0, int S1, int S2, int S3>
-static inline float quad_read(float v) {              // DPP quad_perm: value of lane S[q] of the caller's quad
-  static const int sel[4] = {S0, S1, S2, S3};
-  g_swap[threadIdx.x] = __float_as_int(v);
-  __syncthreads();
-  const int r = g_swap[(threadIdx.x & ~3) + sel[threadIdx.x & 3]];
-  __syncthreads();
-  return __int_as_float(r);
-}
 static inline unsigned wave_umax(unsigned v) {          // maximum over the lane's wave (64 consecutive lanes)
   g_red[threadIdx.x] = v;
   __syncthreads();
