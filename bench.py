@@ -61,6 +61,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the results on their ranks")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances for the all-core CPU baseline (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal only: initialise torch.distributed and run the collectives even with one rank")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (1-GPU box, use with --backend gloo)")
     return ap.parse_args(argv)
@@ -247,8 +249,12 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        # RCCL's version banner (NCCL_DEBUG=VERSION on the GPU boxes) goes to stdout by default: keep stdout for the JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -276,7 +282,7 @@ def run_rank(args):
     use_x_cmd = bool(cfg["kw"].get("vx_cmd"))
     s["use_x_cmd"] = use_x_cmd
     cp = bm.pack_params(mpc, bm.Biped(), half=s["half"])
-    if world > 1:                                   # C0: one parameter block for every rank
+    if use_dist:                                    # C0: one parameter block for every rank
         sharding.broadcast_params(cp, src=0, device=coll_dev)
     solver = bm.BatchSolver(cparams=cp, device=dev_index, max_batch=max(B, total if (strong and rank == 0) else B))
 
@@ -298,7 +304,7 @@ def run_rank(args):
     o_st = torch.empty(B, dtype=torch.int32, device=dev)
     o_nf = torch.empty(B, dtype=torch.int32, device=dev)
     o_rs = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    gather = world > 1 and not args.no_gather
+    gather = use_dist and not args.no_gather
     per = -(-total // world)                        # padded shard length of the all_gather
     if gather:
         g_in = o_u if B == per else torch.zeros((per, h, 12), dtype=torch.float32, device=dev)
@@ -331,7 +337,7 @@ def run_rank(args):
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -350,7 +356,7 @@ def run_rank(args):
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))     # average launch duration, timed region
     if rank == 0:
         _log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms per step, kernel {kernel_ms:.3f} ms")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
@@ -452,7 +458,7 @@ def run_rank(args):
                               "max_abs_err": float(np.abs(got[:len(ref_full)] - ref_full).max()),
                               "u0_max_rel_err": float(rel(got[:, :1], ref_full[:, :1]).max()), "tolerance": 1e-4}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,5 +1,5 @@
 """Convergence soak (GPU box): random batches of the four BASELINE config shapes over a range of seeds; prints the
-instances that did not converge and the worst iteration count.  python tools/soak.py"""
+instances that did not converge and the worst iteration count.  python tools/soak.py [seed_lo seed_hi]"""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import biped_mpc_py_amd as bm
@@ -8,7 +8,7 @@ tot=0; bad=0; worst=0
 for h, gait, kw in ((10,'mixed',dict(vx_cmd=True)), (10,'standing',{}), (16,'walking',dict(vx_cmd=True)), (20,'walking',dict(vx_cmd=True, per_step_mu=True))):
     mpc=bm.MPC(); mpc.h=h
     B=65536 if h==10 else 16384
-    for seed in range(500, 540):
+    for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 500, int(sys.argv[2]) if len(sys.argv) > 2 else 540):
         s=util.synth_batch(B,h,seed,gait=gait,**kw)
         sol=bm.BatchSolver(mpc=mpc, half=s['half'], max_batch=B)
         _,u,info=sol.solve(s['x_fb'],s['foot'],s['contact'],s['phase'],x_cmd=s['x_cmd'],mu=s['mu'],want_states=False)
