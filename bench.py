@@ -16,7 +16,9 @@ backend "nccl" (= RCCL over xGMI).
 
 What a multi-GPU step contains (instances are independent, SURVEY 8(e): no exchange step inside the solve):
   weak   every rank solves its own `--batch` instances, then the results are collected with ONE RCCL
-         all_gather of the controls (the north_star's "gather"); value = N * batch * steps / time.
+         all_gather of the controls (the north_star's "gather"); value = N * batch * steps / time.  The gather
+         of step k is asynchronous and overlaps the solve of step k + 1 (two output buffers), as a production
+         loop would run it; every gather is complete before the timed region ends.
   strong ONE seeded batch of `--total` instances; per step: RCCL broadcast of the ~0.7 KB parameter block,
          every rank solves its contiguous shard, all_gather of the controls; afterwards rank 0 solves the
          whole batch alone and the gathered controls must equal that bit for bit.
@@ -298,7 +300,8 @@ def run_rank(args):
     if rank == 0:
         _log(f"rank 0 of {world}: config {args.config}, h = {h}, {B} instances on this GPU")
     tin = dev_inputs(lo, hi)
-    o_u = torch.empty((B, h, 12), dtype=torch.float32, device=dev)
+    o_u2 = [torch.empty((B, h, 12), dtype=torch.float32, device=dev) for _ in range(2)]   # double buffered: step k's
+    o_u = o_u2[0]                                   # gather overlaps step k + 1's solve
     o_s = torch.empty((B, h, 13), dtype=torch.float32, device=dev)
     o_it = torch.empty(B, dtype=torch.int32, device=dev)
     o_st = torch.empty(B, dtype=torch.int32, device=dev)
@@ -307,17 +310,37 @@ def run_rank(args):
     gather = use_dist and not args.no_gather
     per = -(-total // world)                        # padded shard length of the all_gather
     if gather:
-        g_in = o_u if B == per else torch.zeros((per, h, 12), dtype=torch.float32, device=dev)
-        g_in_c = g_in if args.backend == "nccl" else torch.zeros((per, h, 12), dtype=torch.float32)
-        g_out = torch.empty((world * per, h, 12), dtype=torch.float32, device=coll_dev)
+        g_in2 = [o_u2[i] if B == per else torch.zeros((per, h, 12), dtype=torch.float32, device=dev) for i in range(2)]
+        g_in_c2 = [g_in2[i] if args.backend == "nccl" else torch.zeros((per, h, 12), dtype=torch.float32) for i in range(2)]
+        g_out2 = [torch.empty((world * per, h, 12), dtype=torch.float32, device=coll_dev) for _ in range(2)]
+        g_out = g_out2[0]
+        pending = [None, None]
         if strong:
             pbuf = torch.from_numpy(np.frombuffer(bytes(cp), dtype=np.uint8).copy()).to(coll_dev)
 
     kev = []
+    nstep = [0]
+
+    def drain():
+        """Wait for the collectives still in flight (their buffers are about to be reused / read)."""
+        if gather:
+            for i in range(2):
+                if pending[i] is not None:
+                    pending[i].wait()
+                    pending[i] = None
 
     def step(timed):
+        # Pipelined like a production loop: the all_gather of step k runs on RCCL's stream while step k + 1
+        # solves into the other output buffer; a buffer is reused only after its gather has finished.
+        nonlocal o_u, g_out
+        b = nstep[0] & 1
+        nstep[0] += 1
+        if gather and pending[b] is not None:
+            pending[b].wait()                       # (NCCL: the current stream waits, not the host)
+            pending[b] = None
         if gather and strong:                       # C0 inside the step: the block every rank solves with
             dist.broadcast(pbuf, src=0)
+        o_u = o_u2[b]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -327,15 +350,17 @@ def run_rank(args):
             e1.record()
             kev.append((e0, e1))
         if gather:                                  # C2: every rank receives all controls
-            if g_in is not o_u:
-                g_in[:B].copy_(o_u)
+            g_out = g_out2[b]
+            if g_in2[b] is not o_u:
+                g_in2[b][:B].copy_(o_u)
             if args.backend == "nccl":
-                dist.all_gather_into_tensor(g_out, g_in)
+                pending[b] = dist.all_gather_into_tensor(g_out, g_in2[b], async_op=True)
             else:                                   # rehearsal backend: collectives on host tensors
-                g_in_c.copy_(g_in)
-                dist.all_gather_into_tensor(g_out, g_in_c)
+                g_in_c2[b].copy_(g_in2[b])
+                pending[b] = dist.all_gather_into_tensor(g_out, g_in_c2[b], async_op=True)
 
     def fence():
+        drain()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
