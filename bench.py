@@ -234,6 +234,27 @@ def cpu_baseline(s, h, dt, n_sample):
     return ctrl_full, ctrl_plain, cb
 
 
+class _StdoutToStderr:
+    """File descriptor 1 points at stderr inside the block (C-level output of a library included): stdout is
+    reserved for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import numpy as np
@@ -255,12 +276,12 @@ def run_rank(args):
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        # RCCL's version banner (NCCL_DEBUG=VERSION on the GPU boxes) goes to stdout by default: keep stdout for the JSON line
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        with _StdoutToStderr():                     # RCCL prints its version banner on stdout when the communicator is made
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.barrier()
 
     import biped_mpc_py_amd as bm
     from biped_mpc_py_amd import sharding
