@@ -368,6 +368,38 @@ def solve_mpc(x_fb, t, foot, mpc, biped, contact, half=None, device=0, solver_op
     return states[0], controls[0]
 
 
+def reference_trajectories_batch(x_fb, t, foot, contact, mpc=None, biped=None, x_cmd=None, phase=None, half=None, device=0):
+    """Batched REF:61-109 on the device (the generators phase 1 of the solve kernel runs, exposed through
+    `bmpc_debug_assemble`): x_ref (B,13,h) and foot_ref (B,6,h), fp64, in the reference's row/column order."""
+    from .params import MPC
+    mpc = mpc if mpc is not None else MPC()
+    solver = _cached_solver(mpc, biped, half, device, None)
+    x_fb = np.asarray(x_fb, float).reshape(-1, 12)
+    if phase is None:
+        phase = np.array([phase_index(v, mpc) for v in np.asarray(t, float).reshape(-1)], np.int32)
+    x_ref, foot_ref, _, _ = solver.assemble(x_fb, foot, contact, phase, x_cmd=x_cmd)
+    B, h = x_ref.shape[0], x_ref.shape[1]
+    xr = np.concatenate([x_ref.transpose(0, 2, 1), np.ones((B, 1, h))], axis=1)       # REF:62: 13th row of ones
+    return xr, foot_ref.transpose(0, 2, 1)
+
+
+def get_reference_trajectory(x_fb, mpc, device=0):
+    """Drop-in for REF:61-70: returns x_ref (13,h) fp64."""
+    h = int(mpc.h)
+    xr, _ = reference_trajectories_batch(np.asarray(x_fb, float).reshape(1, 12), [0.0], np.zeros((1, 6)),
+                                         np.ones((1, h, 2), np.uint8), mpc=mpc, device=device)
+    return xr[0]
+
+
+def get_reference_foot_trajectory(x_fb, t, foot, mpc, contact, half=None, device=0):
+    """Drop-in for REF:72-109: returns foot_ref (6,h) fp64 (`contact` as REF:102 reads it: its first row decides)."""
+    h = int(mpc.h)
+    contact = np.asarray(contact)
+    _, fr = reference_trajectories_batch(np.asarray(x_fb, float).reshape(1, 12), [float(t)], np.asarray(foot, float).reshape(1, 6),
+                                         contact[None, :h, :], mpc=mpc, half=half, device=device)
+    return fr[0]
+
+
 def getFootPositionWorld(x_fb, q, biped, mpc=None, device=0):
     """Drop-in for REF:406-424: returns pf_w (6,1) fp64 like the reference."""
     from .params import MPC

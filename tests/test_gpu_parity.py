@@ -590,3 +590,19 @@ def test_closed_loop_rollout_and_warm_start(gait):
     assert np.array_equal(out[True][0], out[False][0])             # the first period starts cold either way
     # measured: 0.60x in double support, 0.84x while the contact schedule advances every period
     assert out[True][1:].mean() < (0.7 if gait == "standing" else 0.95) * out[False][1:].mean()
+
+
+def test_reference_generators_dropin():
+    """`get_reference_trajectory` / `get_reference_foot_trajectory` (REF:61-109) as first-class
+    device-backed functions with the reference's return shapes, against the vectors captured from the reference."""
+    import biped_mpc_py_amd as bm
+    mpc = bm.MPC()
+    for name in ("known_standing", "known_walking_t0"):
+        d = util.load(name)
+        xr = bm.get_reference_trajectory(d["x_fb"], mpc)
+        fr = bm.get_reference_foot_trajectory(d["x_fb"], float(d["t"]), d["foot"], mpc, d["contact"])
+        assert xr.shape == (13, 10) and fr.shape == (6, 10) and xr.dtype == np.float64
+        assert np.abs(xr - d["x_ref"]).max() < 1e-6 and np.abs(fr - d["foot_ref"]).max() < 1e-6
+    d = util.load("cfg4_walking_h10")
+    xr, fr = bm.reference_trajectories_batch(d["x_fb"], d["t"], d["foot"], d["contact"], mpc=mpc, x_cmd=d["x_cmd"])
+    assert np.abs(xr - d["x_ref"]).max() < 1e-6 and np.abs(fr - d["foot_ref"]).max() < 1e-6
