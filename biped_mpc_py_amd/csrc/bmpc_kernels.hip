@@ -174,7 +174,7 @@ struct alignas(16) Smem {
   RT GuT[6][6];
   RT qtl[Dims<H>::NW];       // wrench-space gradient at x = 0 (constant term of gb; only the exact rebuilds read it)
   float eyz[6];              // body y and z axes in the world frame (columns 1, 2 of eul2rotm(x_fb))
-  float red[4][Dims<H>::NWV];
+  float red[2][5][Dims<H>::NWV];
 };
 
 __device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
@@ -195,25 +195,25 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 #endif
-// max over the workgroup of 4 such values at once; the waves combine through LDS.  All threads call.
-template <int NT>
-__device__ __forceinline__ void block_max4(float (&v)[4], float (*red)[NT / 64]) {
+// max over the workgroup of NV such values at once; the waves combine through LDS.  All threads call.  ONE barrier:
+// the caller alternates between two `red` buffers, so a buffer is rewritten only after another barrier.
+template <int NT, int NV>
+__device__ __forceinline__ void block_max(float (&v)[NV], float (*red)[NT / 64]) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(wave_umax(__float_as_uint(v[q])));
+  for (int q = 0; q < NV; ++q) v[q] = __uint_as_float(wave_umax(__float_as_uint(v[q])));
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) red[q][w] = v[q];
+    for (int q = 0; q < NV; ++q) red[q][w] = v[q];
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     unsigned m = __float_as_uint(red[q][0]);
 #pragma unroll
     for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
     v[q] = __uint_as_float(m);
   }
-  __syncthreads();
 }
 
 // out[b] += sum_q w[q] * M[q][b] for a 6x6 f64 matrix in LDS: whole rows are fetched (three 16-byte
@@ -965,7 +965,7 @@ solve_kernel(const DevParams P, const int B,
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
   int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
-  int n_check = 0;
+  int n_check = 0, n_red = 0;
   constexpr int REFRESH_CHECKS = 2;            // identical iterates and parity for 1, 2 and 4 on every test set
   int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
   while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
@@ -1261,51 +1261,54 @@ solve_kernel(const DevParams P, const int B,
     gbl -= alpha * (RT)ginc;
     ++it;
     BMPC_STAMP(5)
-    // --- stopping test (workgroup-uniform); the carried products are rebuilt from x first
-    if (check_now) {
-      next_check += P.check_every;
-      float v4[4] = {rp, rs, nz, nx};
-      block_max4<NT>(v4, sm.red);
-      res_p = v4[0];
-      res_s = v4[1];
-      const bool bad = !(v4[0] == v4[0]) || !(v4[1] == v4[1]) || !(v4[3] < 3.0e38f);
-      const bool done = v4[0] <= P.eps_pri * fmaxf(1.f, v4[2]) && v4[1] <= P.eps_dua * fmaxf(1.f, v4[3]);
-      // the exact rebuild of the carried products: before leaving (the outputs use it) and at every
-      // REFRESH_CHECKS-th test otherwise
-      ++n_check;
-      if (bad || done || it == P.max_iter || n_check % REFRESH_CHECKS == 0) refresh();
-      if (bad) { status = 2; break; }
-      if (done) { status = 0; break; }
+    // --- stopping test and penalty re-classification (workgroup-uniform decisions).  Both need a reduction over
+    // the workgroup; a re-classification always falls on a stopping test with the default periods, and the two
+    // share ONE exchange: the residual statistics and the "some penalty moves" flag are reduced together.
+    const bool adapt_now = (it == next_adapt);
+    if (adapt_now) next_adapt += P.adapt_every;
+    const bool adapt_do = adapt_now && nfac <= P.max_refactor;
+    // Damping: an instance that is still re-classifying after many rounds is cycling between active sets
+    // (about one in a million at kappa = 20); smaller moves break the cycle (sqrt(kappa) after 10
+    // factorisations, its square root after 16), where stopping the adaptation would leave hundreds of
+    // plain-ADMM iterations.
+    auto reclassify = [&](float& nb, float& ng) {
+      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
+      const bool actb = (zb <= (RT)lb || zb >= (RT)ub) && yb != (RT)0;
+      const bool actg = (zg >= (RT)0) && yg != (RT)0;
+      // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
+      const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+      nb = eqb ? P.rho_eq : (actb ? fminf(rvb * kap, hib) : fmaxf(rvb / kap, P.rho_lo));
+      ng = actg ? fminf(rvg * kap, hig) : fmaxf(rvg / kap, P.rho_lo);
+    };
+    float chg = 0.f;
+    if (adapt_do) {
+      float nb, ng;
+      reclassify(nb, ng);
+      chg = ((nb != rvb) | (ng != rvg)) ? 1.f : 0.f;
     }
-    // --- penalty re-classification by the current active set
-    if (it == next_adapt) {
-      next_adapt += P.adapt_every;
-      if (nfac <= P.max_refactor) {
-        int changed = 0;
-        float nb = 0.f, ng = 0.f;
-        // Damping: an instance that is still re-classifying after many rounds is cycling between active sets
-        // (about one in a million at kappa = 20); smaller moves break the cycle (sqrt(kappa) after 10
-        // factorisations, its square root after 16), where stopping the adaptation would leave hundreds of
-        // plain-ADMM iterations.
-        const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
-        if (valid) {
-          const bool actb = (zb <= (RT)lb || zb >= (RT)ub) && yb != (RT)0;
-          const bool actg = (zg >= (RT)0) && yg != (RT)0;
-          // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
-          const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-          const float ob = rvb, og = rvg;
-          nb = eqb ? P.rho_eq : (actb ? fminf(ob * kap, hib) : fmaxf(ob / kap, P.rho_lo));
-          ng = actg ? fminf(og * kap, hig) : fmaxf(og / kap, P.rho_lo);
-          changed = (nb != ob) | (ng != og);
-        }
-        changed = __syncthreads_or(changed);
-        if (changed) {
-          if (valid) {
-            rvb = nb; rvg = ng;
-            irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
-          }
-          need_factor = true;
-        }
+    if (check_now || adapt_do) {
+      float v5[5] = {rp, rs, nz, nx, chg};
+      block_max<NT, 5>(v5, sm.red[n_red & 1]);
+      ++n_red;
+      if (check_now) {
+        next_check += P.check_every;
+        res_p = v5[0];
+        res_s = v5[1];
+        const bool bad = !(v5[0] == v5[0]) || !(v5[1] == v5[1]) || !(v5[3] < 3.0e38f);
+        const bool done = v5[0] <= P.eps_pri * fmaxf(1.f, v5[2]) && v5[1] <= P.eps_dua * fmaxf(1.f, v5[3]);
+        // the exact rebuild of the carried products: before leaving (the outputs use it) and at every
+        // REFRESH_CHECKS-th test otherwise
+        ++n_check;
+        if (bad || done || it == P.max_iter || n_check % REFRESH_CHECKS == 0) refresh();
+        if (bad) { status = 2; break; }
+        if (done) { status = 0; break; }
+      }
+      if (adapt_do && v5[4] > 0.f) {           // (the new penalties are formed again rather than kept across the barrier)
+        float nb, ng;
+        reclassify(nb, ng);
+        rvb = nb; rvg = ng;
+        irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
+        need_factor = true;
       }
     }
     BMPC_STAMP(6)
