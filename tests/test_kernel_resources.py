@@ -34,7 +34,7 @@ def test_no_spills_and_two_waves_per_simd(tmp_path):
         assert int(meta["vgpr_count"]) + meta["agpr_count"] <= 256, (h, meta)      # two waves per SIMD
         lds = int(meta["group_segment_fixed_size"])
         waves = {10: 2, 16: 3, 20: 4}[h]
-        assert (160 * 1024 // lds) * waves >= 8, (h, lds)                     # LDS lets 8 waves live on a CU
+        assert 160 * 1024 // lds >= 8 // waves, (h, lds)       # LDS admits the instances the 8 wave slots of a CU can hold
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
