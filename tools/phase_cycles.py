@@ -4,10 +4,16 @@ import biped_mpc_py_amd as bm
 from biped_mpc_py_amd import _lib
 from biped_mpc_py_amd.synth import synth_batch
 B=int(sys.argv[1]) if len(sys.argv)>1 else 256
-h=10
-s=bm.BatchSolver(max_batch=B)
-_s=synth_batch(B,h,1)
+cfg=int(sys.argv[2]) if len(sys.argv)>2 else 2        # BASELINE config: 2 (h=10), 3 (h=16), 5 (h=20)
+from biped_mpc_py_amd.synth import CONFIGS
+_c=CONFIGS[cfg]
+h=_c["h"]
+_s=synth_batch(B,h,_c["seed"],gait=_c["gait"],**_c["kw"])
+_m=bm.MPC(); _m.h=h
+s=bm.BatchSolver(mpc=_m,half=_s["half"],max_batch=B)
 x,f,c,p=_s["x_fb"].astype(np.float32),_s["foot"].astype(np.float32),_s["contact"],_s["phase"]
+xc=torch.from_numpy(_s["x_cmd"].astype(np.float32)).cuda()
+mu=None if _s["mu"] is None else torch.from_numpy(_s["mu"].astype(np.float32)).cuda()
 dev=torch.device('cuda',0)
 prof=torch.zeros((B,16),dtype=torch.int64,device=dev)
 _lib.check(s._lib.bmpc_debug_set_profile(s._h, prof.data_ptr()))
@@ -15,9 +21,9 @@ tx,tf,tc,tp=[torch.from_numpy(a).to(dev) for a in (x,f,c,p)]
 st=torch.cuda.Stream()
 with torch.cuda.stream(st):
     for _ in range(3):
-        s.solve_device(tx,tf,tc,tp)
+        s.solve_device(tx,tf,tc,tp,xc,mu)
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
-    e0.record(); s.solve_device(tx,tf,tc,tp); e1.record()
+    e0.record(); s.solve_device(tx,tf,tc,tp,xc,mu); e1.record()
 torch.cuda.synchronize()
 pr=prof.cpu().numpy().astype(float)
 print('B',B,'kernel ms',e0.elapsed_time(e1))
