@@ -34,14 +34,10 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
-#include <type_traits>
 
 namespace bmpc {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-#ifndef BMPC_EMU
-typedef float f4v __attribute__((ext_vector_type(4)));   // one 16 x 16 accumulator tile of v_mfma_f32_16x16x4_f32
-#endif
 typedef double RT;                       // iterate / residual / block-algebra arithmetic
 
 #ifndef BMPC_EMU
@@ -55,13 +51,6 @@ __device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_upda
 // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
 // redone there instead of being hoisted into a second, f64, register copy that lives across the loop
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
-// C (16 x 16, 4 registers: lane (g, c) = (lane / 16, lane % 16) holds rows 4 g + i of column c) +=
-// A (16 x 4: lane (g, c) supplies A[c][g]) x B (4 x 16: lane (g, c) supplies B[g][c]), all f32
-__device__ __forceinline__ void mfma_16x16x4(float a, float b, f4v& c) { c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-// LDS traffic between lanes of ONE wave needs no s_barrier (a wave's DS operations execute in order); this only
-// keeps the compiler from moving code across
-#define BMPC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-__device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }   // ds_add_f32, no return value
 #endif
 __device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
@@ -118,12 +107,7 @@ struct Dims {
   // the two addresses of a wave's ds_read_b128 (even lanes: half 0, odd lanes: half 1) never share a bank.
   static constexpr int HNP = ((HN + 3) / 4) * 4;
   static constexpr int VL = 2 * HNP;
-  // dense sweep on the matrix cores: the 6H x 6H matrix padded with an identity to NP = 16 NB, wave w owning the
-  // 16-row blocks 2 w and 2 w + 1 (= the rows of its own lanes) as 2 NB accumulator tiles
-  static constexpr int NB = 2 * NWV;
-  static constexpr int NP = 16 * NB;
-  static constexpr int SLD = NP + 4;                     // row stride (floats) of the staging image of a wave's 32 rows
-  static_assert(NP >= NW && NP - NW < 16 && NW % 4 == 0, "padding stays inside the last 16-block; four pivots per step");
+  static constexpr int PVS = ((VL + NW + 3) / 4) * 4;    // one published pivot column: two-half vector + one dump slot per row
   static_assert(HNP % 64 >= 4 && HNP % 64 <= 60, "halves of a two-half vector would collide on LDS banks");
   // Gt row half: 3 component groups x HH steps, padded to whole float4s
   static constexpr int GH = ((3 * HH + 3) / 4) * 4;
@@ -166,11 +150,9 @@ struct alignas(16) Smem {
     IterScratch<H> itv;
   } u;
   RT xs[H][2][6];            // x (relaxed iterate) for the exact rebuilds and the state roll-out
-  // the four pivot rows of a sweep step (= pivot columns, by symmetry), double buffered: piv[parity][column] =
-  // {V[k][column], ..., V[k + 3][column]}, with P - I in the pivot columns themselves
-  alignas(16) float4 piv[2][Dims<H>::NP];
-  // ... and the exact diagonal of P beside it (P_kk - 1 loses the low bits of a small pivot)
-  alignas(16) float4 pdg[2];
+  // the two pivot columns of a sweep step, double buffered, two-half layout; behind each one dump slot per row:
+  // the half-1 lanes, which hold no pivot-column entry, store there instead of branching around the store
+  alignas(16) float piv[2][2 * Dims<H>::PVS];
   alignas(16) float dsc[Dims<H>::VL];      // Jacobi scaling of the current factorisation
   // block-diagonal part of K^-1.  Foot-major: a lane's row sits at 48 B x row + const.
   // Each entry is a pair {factor, G_f x factor}: the step d and its general-row image G_f d are the same dot
@@ -870,205 +852,98 @@ solve_kernel(const DevParams P, const int B,
         }
       }
     }
-    // Symmetric sweep on the matrix cores, FOUR pivots per step (v_mfma_f32_16x16x4_f32).  The scaled matrix,
-    // padded with an identity to NP = 16 NB, is held as 16 x 16 accumulator tiles, wave w owning the tile rows
-    // 2 w and 2 w + 1 -- the rows of its own lanes; the change of layout (row halves <-> tiles) goes through LDS one
-    // wave at a time (a wave writes its 32 rows and reads them back in the other layout: the row halves are
-    // dead before the tiles are live, which is what keeps the kernel under 256 registers).  Step S = {k .. k + 3},
-    // P = V[S, S]: the lanes that hold the pivot ROWS publish them (one float4 per column: by symmetry these are
-    // also the pivot columns) with P - I in the columns S; one barrier; every lane inverts P (2 x 2 blocks, two
-    // reciprocals; lane group g keeps column g of P^-1), forms A = -(V[r, S] P^-1)[g] for its two tile rows and
-    // takes B = the published rows, and ONE MFMA per tile performs
-    //    V <- V - T V[S, :],   T = V[:, S] P^-1,
-    // where P - I in the columns S makes the pivot rows come out as P^-1 V[S, :] ((P - I)[q, :] P^-1 = e_q -
-    // P^-1[q, :]: no special case), leaves T itself in the columns S (the swept pivot columns) and 2 I - P^-1 in
-    // the pivot block.  Nothing reads that block as an operand again, so the 2 I is removed once, on the way
-    // back to the row halves (-P^-1 as in the vector sweep this replaces: 24.5 k -> see DESIGN.md section 6).
-    // The MFMAs of the tile row that holds the NEXT pivots are issued first and its rows published at once into
-    // the other buffer; the remaining MFMAs run under the publication, the barrier and the next step's inverse.
-    {
-      constexpr int NB = Dims<H>::NB, NP = Dims<H>::NP, NWV = Dims<H>::NWV, SLD = Dims<H>::SLD;
-      static_assert(sizeof(sm.u.fac) >= 32 * SLD * sizeof(float), "one wave's 32 rows fit the factor scratch");
-      const int w = l >> 6, g_ = (l >> 4) & 3, c_ = l & 15;
-      const int rowr = row - 32 * w;                        // own row within the wave's 32 (clones: the row they clone)
-      float* S = reinterpret_cast<float*>(&sm.u.fac);      // (the block algebra is done with this region)
-      f4v acc[2][NB];
-      const int g = g_, c = c_;
-      // row halves -> tiles, the waves taking turns at the staging region: wave w passes w barriers, stages (code
-      // that is unconditional for the wave, so the row halves are dead before the tiles are defined), and passes
-      // the remaining NWV - w (s_barrier counts arrivals, whatever the program counter)
-      for (int i = 0; i < w; ++i) __syncthreads();
-      {
-        float* dst = &S[rowr * SLD + hf * HN];
-#pragma unroll
-        for (int q = 0; q < HN / 2; ++q) *reinterpret_cast<float2*>(&dst[2 * q]) = float2{Vr[q].x, Vr[q].y};
-        BMPC_WAVE_SYNC();
-        const float* src = &S[4 * g * SLD + c];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int J = 0; J < NB; ++J)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[a][J][i] = src[(16 * a + i) * SLD + 16 * J];
-      }
-      for (int i = w; i < NWV; ++i) __syncthreads();
-      if constexpr (NP > NW) {                               // identity padding (the staged values there are stale)
-        constexpr int CL = NW - 16 * (NB - 1);               // first padding row / column within the last 16-block
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bool prow = w == NWV - 1 && a == 1 && 4 * g + i >= CL;
-            const float x = acc[a][NB - 1][i];
-            acc[a][NB - 1][i] = (c >= CL || prow) ? ((prow && c == 4 * g + i) ? 1.f : 0.f) : x;
-          }
-        if (w == NWV - 1) {
-#pragma unroll
-          for (int J = 0; J < NB - 1; ++J)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[1][J][i] = (4 * g + i >= CL) ? 0.f : acc[1][J][i];
-        }
-      }
-      if (w == 0 && g == 0) {                                // rows 0 .. 3
-#pragma unroll
-        for (int J = 0; J < NB; ++J) sm.piv[0][16 * J + c] = float4{acc[0][J][0], acc[0][J][1], acc[0][J][2], acc[0][J][3]};
-        if (c < 4) {
-          const f4v d = acc[0][0];
-          reinterpret_cast<float*>(&sm.pdg[0])[c] = c == 0 ? d[0] : (c == 1 ? d[1] : (c == 2 ? d[2] : d[3]));
-          lds_add(&reinterpret_cast<float*>(sm.piv[0])[4 * c + c], -1.f);
-        }
-      }
-      int par = 0;
-      auto step = [&](auto ipc, const int t, const bool last) __attribute__((always_inline)) {
-        constexpr int IP = decltype(ipc)::value;             // step 8 t + IP: pivots 32 t + 4 IP .. + 3, rows of wave t
-        constexpr int AN = ((IP + 1) / 4) % 2, GN = (IP + 1) % 4;   // tile row and lane group of the next pivots ...
-        const int wn = IP == 7 ? t + 1 : t;                  // ... and their wave
-        const int k0 = 32 * t + 4 * IP;
-        const float4* R = sm.piv[par];
-        float4* Rn = sm.piv[par ^ 1];
-        const float4* Dg = &sm.pdg[par];
-        float* Dn = reinterpret_cast<float*>(&sm.pdg[par ^ 1]);
-        par ^= 1;
-        // (opaque copies of the lane's indices: the addresses and lane masks below are re-made in every step
-        // instead of living in registers across the iteration loop)
-        int g = g_, c = c_;
-        BMPC_OPAQUE(g);
-        BMPC_OPAQUE(c);
-        __syncthreads();
-        constexpr int NH = NB / 2;                           // the B operands are fetched in two halves (registers)
-        float4 cc[2];
-        float bg[NH];
-        float2 bxy[NH];
-        const float4 pd = *Dg;                               // diagonal of P (exact)
-        const float p01 = reinterpret_cast<const float*>(&R[k0 + 1])[0];
-        const float2 pb2 = *reinterpret_cast<const float2*>(&R[k0 + 2]);          // P[0][2], P[1][2]
-        const float4 pb3 = R[k0 + 3];                                             // P[0][3], P[1][3], P[2][3]
-#pragma unroll
-        for (int a = 0; a < 2; ++a) cc[a] = R[32 * w + 16 * a + c];     // V[r][S] of the row this lane supplies A for
-#pragma unroll
-        for (int J = 0; J < NH; ++J) {
-          bg[J] = reinterpret_cast<const float*>(&R[16 * J + c])[g];
-          bxy[J] = *reinterpret_cast<const float2*>(&R[16 * J + c]);
-        }
-        BMPC_SCHED_BARRIER();
-        // P = [[A, B], [B', D]] is eliminated as TWO consecutive 2 x 2 pivots fused into one rank-4 update -- the
-        // small quantities of the second pivot (its rows and columns after the first, S = D - B' A^-1 B) are formed
-        // explicitly before anything is multiplied by S^-1; applying the 4 x 4 inverse [A^-1 + Y S^-1 Y', ...]
-        // instead cancels them away in f32 (|V K - I| of order 1 on matrices with penalties spread over 6 decades)
-        const float p00 = pd.x, p11 = pd.y, p22 = pd.z, p33 = pd.w, p02 = pb2.x, p12 = pb2.y, p03 = pb3.x, p13 = pb3.y,
-                    p23 = pb3.z;
-        const float r1 = rcp_approx(p00 * p11 - p01 * p01);
-        const float a00 = p11 * r1, a01 = -p01 * r1, a11 = p00 * r1;                        // A^-1
-        const float y00 = a00 * p02 + a01 * p12, y01 = a00 * p03 + a01 * p13, y10 = a01 * p02 + a11 * p12,
-                    y11 = a01 * p03 + a11 * p13;                                            // Y = A^-1 B
-        const float s00 = p22 - (p02 * y00 + p12 * y10), s01 = p23 - (p02 * y01 + p12 * y11),
-                    s11 = p33 - (p03 * y01 + p13 * y11);                                    // S
-        const float r2 = rcp_approx(s00 * s11 - s01 * s01);
-        const float i00 = s11 * r2, i01 = -s01 * r2, i11 = s00 * r2;                        // S^-1
-        // lane group g supplies k = g: g < 2 the first pivot pair (multipliers V[r, A] A^-1, rows V[A, :]), g >= 2
-        // the second (multipliers (V[r, D] - V[r, A] Y) S^-1, rows V[D, :] - Y' V[A, :]); with P - I in the
-        // published pivot columns the pivot rows themselves need no special case
-        const bool hi = g >= 2, e1 = (g & 1) != 0;
-        const float ya = hi ? (e1 ? y01 : y00) : 0.f, yb = hi ? (e1 ? y11 : y10) : 0.f;     // Y[:, g - 2]
-        const float c0 = hi ? (e1 ? i01 : i00) : (e1 ? a01 : a00), c1 = hi ? (e1 ? i11 : i01) : (e1 ? a11 : a01);
-        float Aop[2], bv[NB];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const float d0 = cc[a].z - (y00 * cc[a].x + y10 * cc[a].y), d1 = cc[a].w - (y01 * cc[a].x + y11 * cc[a].y);
-          const float u0 = hi ? d0 : cc[a].x, u1 = hi ? d1 : cc[a].y;
-          Aop[a] = -(u0 * c0 + u1 * c1);
-        }
-        BMPC_SCHED_BARRIER();
-        float bg2[NB - NH];
-        float2 bxy2[NB - NH];
-#pragma unroll
-        for (int J = NH; J < NB; ++J) {                      // second half: in flight under the first half's MFMAs
-          bg2[J - NH] = reinterpret_cast<const float*>(&R[16 * J + c])[g];
-          bxy2[J - NH] = *reinterpret_cast<const float2*>(&R[16 * J + c]);
-        }
-#pragma unroll
-        for (int J = 0; J < NH; ++J) bv[J] = bg[J] - (ya * bxy[J].x + yb * bxy[J].y);
-#pragma unroll
-        for (int J = 0; J < NH; ++J) mfma_16x16x4(Aop[AN], bv[J], acc[AN][J]);
-        BMPC_SCHED_BARRIER();
-#pragma unroll
-        for (int J = NH; J < NB; ++J) bv[J] = bg2[J - NH] - (ya * bxy2[J - NH].x + yb * bxy2[J - NH].y);
-#pragma unroll
-        for (int J = NH; J < NB; ++J) mfma_16x16x4(Aop[AN], bv[J], acc[AN][J]);
-        if (!last && w == wn && g == GN) {
-#pragma unroll
-          for (int J = 0; J < NB; ++J) Rn[16 * J + c] = float4{acc[AN][J][0], acc[AN][J][1], acc[AN][J][2], acc[AN][J][3]};
-          if ((c >> 2) == GN) {                              // the diagonal of the next pivot block: exact copy, then P - I
-            // (tile column = tile row of the pivots: 2 wn + AN.  The component is chosen per candidate tile first,
-            // through opaque copies: a select between tiles would otherwise become a select between ADDRESSES and
-            // put the whole accumulator array into scratch memory)
-            const int k = c & 3;
-            float dk = 0.f;
-#pragma unroll
-            for (int u = 0; u < NWV; ++u) {
-              float d0 = acc[AN][AN + 2 * u][0], d1 = acc[AN][AN + 2 * u][1], d2 = acc[AN][AN + 2 * u][2], d3 = acc[AN][AN + 2 * u][3];
-              BMPC_OPAQUE(d0); BMPC_OPAQUE(d1); BMPC_OPAQUE(d2); BMPC_OPAQUE(d3);
-              const float du = k == 0 ? d0 : (k == 1 ? d1 : (k == 2 ? d2 : d3));
-              dk = wn == u ? du : dk;
-            }
-            Dn[k] = dk;
-            lds_add(&reinterpret_cast<float*>(Rn)[4 * (k0 + 4 - 4 * GN + c) + k], -1.f);
-          }
-        }
-#pragma unroll
-        for (int J = 0; J < NB; ++J) mfma_16x16x4(Aop[1 - AN], bv[J], acc[1 - AN][J]);
-      };
+    // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of half hf
+    // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always one static register pair
+    // of the half-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the half-0 lanes publish their two entries of the
+    // pivot columns (= pivot rows, by symmetry), every lane fetches the 2 HN entries of its half, forms its
+    // T[r, :] = V[r, S] P^-1 and updates with TWO packed FMAs per register pair:  row -= T[r, 0] row_k +
+    // T[r, 1] row_k+1; the pivot rows themselves use T[r, :] = e_r - P^-1[r, :], which turns them into
+    // P^-1 V[S, :] (exact up to rounding because the scaled pivots are <= 1; no second multiply, and a row is
+    // never rebuilt from a column -- measured asymmetry 2e-7, same accuracy as the re-symmetrising form).
+    // The entries in the columns S become T (V[r, S] P^-1) and, in the pivot block, -P^-1.
+    // Two pivots per barrier and LDS round trip instead of one; the update of the NEXT pair of pivot columns
+    // is done first and published at once (into the other buffer), so that its round trip overlaps with the
+    // rest of this step's updates.
+    constexpr int U = 6;
+    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
+    constexpr int PVS = Dims<H>::PVS;            // floats per published column (two-half layout + dump slots)
+    int pos = row;                              // rotated index of the own row (group 0)
+    int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
+    sm.piv[0][ws] = Vr[0].x;
+    sm.piv[0][PVS + ws] = Vr[0].y;
+    int par = 0;                                // buffer of the current step (a group has an odd number of steps)
 #pragma unroll 1
-      for (int t = 0; t < NWV; ++t) {
-        const int left = NW / 4 - 8 * t;                     // steps left (workgroup-uniform)
-        step(std::integral_constant<int, 0>{}, t, left == 1);
-        if (left > 1) step(std::integral_constant<int, 1>{}, t, left == 2);
-        if (left > 2) step(std::integral_constant<int, 2>{}, t, left == 3);
-        if (left > 3) step(std::integral_constant<int, 3>{}, t, left == 4);
-        if (left > 4) step(std::integral_constant<int, 4>{}, t, left == 5);
-        if (left > 5) step(std::integral_constant<int, 5>{}, t, left == 6);
-        if (left > 6) step(std::integral_constant<int, 6>{}, t, left == 7);
-        if (left > 7) step(std::integral_constant<int, 7>{}, t, left == 8);
+    for (int k0 = 0; k0 < NW; k0 += U) {
+      const int ps = slot<H>(pos);
+      int posn = pos - U;                       // ... and in the next group
+      posn += (posn < 0) ? NW : 0;
+      const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
+#pragma unroll
+      for (int u = 0; u < U; u += 2) {
+        const float* bA = sm.piv[par];                   // column k
+        const float* bB = bA + PVS;                      // column k + 1
+        float* nA = sm.piv[par ^ 1];
+        par ^= 1;
+        const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
+        __syncthreads();
+        const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
+        const float p11 = bB[u + 1];
+        const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
+        BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
+        const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
+        const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
+        const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
+        float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
+        t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
+        t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
+        const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
+        // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the
+        // next pivot columns first
+        constexpr int CH = HN <= 32 ? HN : 16;
+        static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
+#pragma unroll
+        for (int c0i = 0; c0i < HN; c0i += CH) {
+          const int c1i = c0i + CH < HN ? c0i + CH : HN;
+          f2 pa[CH / 2], pb[CH / 2];
+#pragma unroll
+          for (int q = c0i; q < c1i; q += 4) {
+            if (q + 4 <= c1i) {
+              const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
+              const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
+              pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
+            } else {
+              const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
+              const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
+              pa[(q - c0i) / 2] = f2{a2.x, a2.y};
+              pb[(q - c0i) / 2] = f2{b2.x, b2.y};
+            }
+          }
+          if (c0i == 0) {
+            static_assert(U / 2 + 1 <= CH / 2, "the next pivot pair lies in the first chunk");
+            Vr[un] = __builtin_elementwise_fma(m1, pb[un], __builtin_elementwise_fma(m0, pa[un], Vr[un]));
+            const int wn = u + 2 < U ? ws : wsn;         // (after the very last step: columns nobody reads)
+            nA[wn] = Vr[un].x;
+            nA[PVS + wn] = Vr[un].y;
+          }
+#pragma unroll
+          for (int r = c0i / 2; r < c1i / 2; ++r)
+            if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
+          if (c1i < HN) BMPC_FENCE();
+        }
+        if (hf == 0) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
       }
-      for (int i = 0; i < w; ++i) __syncthreads();           // tiles -> row halves, in turns as above
-      {
-        float* dst = &S[4 * g * SLD + c];
+      {                                        // rotate left by U across the pair
+        f2 tmp[U / 2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < U / 2; ++u) tmp[u] = pair_swap(Vr[u]);
 #pragma unroll
-          for (int J = 0; J < NB; ++J)
+        for (int r = 0; r + U / 2 < HN / 2; ++r) Vr[r] = Vr[r + U / 2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[(16 * a + i) * SLD + 16 * J] = acc[a][J][i];
-        BMPC_WAVE_SYNC();
-        if (real && hf == 0) lds_add(&S[rowr * SLD + row], -2.f);        // 2 I - P^-1 -> -P^-1 on the diagonal
-        BMPC_WAVE_SYNC();
-        const float* src = &S[rowr * SLD + hf * HN];
-#pragma unroll
-        for (int q = 0; q < HN / 2; ++q) { const float2 x = *reinterpret_cast<const float2*>(&src[2 * q]); Vr[q] = f2{x.x, x.y}; }
+        for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
       }
-      // (the last of these barriers also separates the staging from the iteration's exchange vectors, which share
-      // this LDS region)
-      for (int i = w; i < NWV; ++i) __syncthreads();
+      pos = posn;
+      ws = wsn;
     }
     if (dbg.prof) t_sweep += clock64() - t_mark;
   };

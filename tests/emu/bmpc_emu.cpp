@@ -27,11 +27,9 @@
 struct emu_idx { int x; };
 static thread_local emu_idx threadIdx, blockIdx;
 static std::barrier<>* g_bar = nullptr;
-static std::barrier<>* g_wbar[16] = {};       // one per wave: synchronisation among the 64 lanes of a wave
 static int g_or[2];
 static int g_swap[1024];
 static unsigned g_red[1024];
-static float g_ma[1024], g_mb[1024];
 
 static inline void __syncthreads() { g_bar->arrive_and_wait(); }
 static inline int __syncthreads_or(int v) {
@@ -83,24 +81,7 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
   __syncthreads();
   return m;
 }
-// v_mfma_f32_16x16x4_f32 of the lane's wave: C[4 g + i][c] += sum_k A[4 g + i][k] B[k][c], lane (g', c') supplying
-// A[c'][g'] and B[g'][c']
-typedef float f4v __attribute__((ext_vector_type(4)));
-static inline void mfma_16x16x4(float a, float b, f4v& c) {
-  g_ma[threadIdx.x] = a;
-  g_mb[threadIdx.x] = b;
-  __syncthreads();
-  const int w0 = threadIdx.x & ~63, ln = threadIdx.x & 63, g = ln >> 4, cc = ln & 15;
-  for (int i = 0; i < 4; ++i) {
-    float acc = c[i];
-    for (int k = 0; k < 4; ++k) acc = std::fmaf(g_ma[w0 + 16 * k + 4 * g + i], g_mb[w0 + 16 * k + cc], acc);
-    c[i] = acc;
-  }
-  __syncthreads();
-}
-static inline void lds_add(float* p, float v) { *p += v; }     // (one lane per address between two synchronisations)
 }  // namespace bmpc
-#define BMPC_WAVE_SYNC() g_wbar[threadIdx.x >> 6]->arrive_and_wait()
 #define BMPC_FENCE() do { } while (0)
 #define BMPC_OPAQUE(x) do { } while (0)
 #define BMPC_SCHED_BARRIER() do { } while (0)
@@ -118,8 +99,6 @@ void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot
   for (int b = 0; b < B; ++b) {
     std::barrier<> bar(NT);
     g_bar = &bar;
-    std::vector<std::unique_ptr<std::barrier<>>> wb;
-    for (int w = 0; w < NT / 64; ++w) { wb.emplace_back(new std::barrier<>(64)); g_wbar[w] = wb.back().get(); }
     g_or[0] = g_or[1] = 0;
     std::vector<std::thread> th;
     th.reserve(NT);
