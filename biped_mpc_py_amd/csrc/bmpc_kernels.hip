@@ -964,9 +964,17 @@ solve_kernel(const DevParams P, const int B,
   RT axg = 0, gbl = qt;                       // x = 0: b = 0, gb = qt
   const RT alpha = (RT)P.alpha;
   int it = 0, status = 1;
-  int next_check = P.check_every > 0 ? P.check_every : 1;                       // counters instead of modulos
-  int n_check = 0, n_red = 0;
-  constexpr int REFRESH_CHECKS = 2;            // identical iterates and parity for 1, 2 and 4 on every test set
+  // counters instead of modulos; a cold start cannot pass the first test (check_every iterations in): it is skipped
+  const int check_every = P.check_every > 0 ? P.check_every : 1;
+  int next_check = 2 * check_every;
+  int n_red = 0;
+  // exact rebuild of the carried products every REFRESH_ITERS iterations (at the first stopping test from there
+  // on; identical iterates and parity for a rebuild at every test, every second and every fourth on every test set)
+  constexpr int REFRESH_ITERS = 20;
+  int next_refresh = REFRESH_ITERS;
+  // a stopping test that finds a residual more than FAR times its tolerance away cannot be followed by a
+  // successful one check_every iterations later (the tail contracts by ~6 per 5 iterations): the next one is skipped
+  constexpr float FAR = 1.0e3f;
   int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
   while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
   float res_p = 0.f, res_s = 0.f;
@@ -1055,6 +1063,7 @@ solve_kernel(const DevParams P, const int B,
     }
     refresh();                                 // axg, gbl of the loaded x (barriers inside: all lanes)
     if (ok && warm.adapt_start > 0 && P.adapt_every > 0) next_adapt = warm.adapt_start;
+    if (ok) next_check = check_every;
   }
 
 #pragma unroll 1
@@ -1291,15 +1300,18 @@ solve_kernel(const DevParams P, const int B,
       block_max<NT, 5>(v5, sm.red[n_red & 1]);
       ++n_red;
       if (check_now) {
-        next_check += P.check_every;
         res_p = v5[0];
         res_s = v5[1];
+        const float tol_p = P.eps_pri * fmaxf(1.f, v5[2]), tol_s = P.eps_dua * fmaxf(1.f, v5[3]);
         const bool bad = !(v5[0] == v5[0]) || !(v5[1] == v5[1]) || !(v5[3] < 3.0e38f);
-        const bool done = v5[0] <= P.eps_pri * fmaxf(1.f, v5[2]) && v5[1] <= P.eps_dua * fmaxf(1.f, v5[3]);
-        // the exact rebuild of the carried products: before leaving (the outputs use it) and at every
-        // REFRESH_CHECKS-th test otherwise
-        ++n_check;
-        if (bad || done || it == P.max_iter || n_check % REFRESH_CHECKS == 0) refresh();
+        const bool done = v5[0] <= tol_p && v5[1] <= tol_s;
+        const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
+        next_check += far ? 2 * check_every : check_every;
+        // the exact rebuild of the carried products: before leaving (the outputs use it) and every
+        // REFRESH_ITERS iterations otherwise
+        const bool rebuild = it >= next_refresh;
+        if (rebuild) next_refresh = it + REFRESH_ITERS;
+        if (bad || done || it == P.max_iter || rebuild) refresh();
         if (bad) { status = 2; break; }
         if (done) { status = 0; break; }
       }
