@@ -139,8 +139,12 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
     warm.theta = hd->warm_theta;
     warm.adapt_start = hd->params.warm_adapt_start;
   }
-  hipLaunchKernelGGL((bmpc::solve_kernel<H>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
-                     phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
+  if (dbg.prof)     // diagnostics build of the same body: in-kernel cycle stamps (bmpc_debug_set_profile)
+    hipLaunchKernelGGL((bmpc::solve_kernel_prof<H>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
+                       phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
+  else
+    hipLaunchKernelGGL((bmpc::solve_kernel<H>), dim3(B), dim3(NT), 0, st, hd->dev, B, x_fb, foot, contact,
+                       phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
   HIP_TRY(hipGetLastError());
   if (warm.buf) { hd->warm_valid = true; hd->warm_batch = B; }
   return BMPC_OK;

@@ -46,6 +46,21 @@ __device__ __forceinline__ float rcp_approx(float x) { return __builtin_amdgcn_r
 __device__ __forceinline__ float rsq_approx(float x) { return __builtin_amdgcn_rsqf(x); }
 // value of the other lane of the pair (lane ^ 1): DPP quad_perm [1, 0, 3, 2].  Call with all lanes active.
 __device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+// Workgroup barrier.  __syncthreads() alone is not enough here: its release fence should make the compiler wait for
+// the wave's outstanding LDS operations (s_waitcnt lgkmcnt(0)) before s_barrier, but ROCm 7.2's hipcc leaves that
+// wait out at the top of the sweep loop, whose back edge carries a pending ds_write (the publication of the next
+// pivot columns) -- the other wave then reads the pivot buffer before the store has landed.  Seen on MI355X as
+// results that change from run to run once two waves share a SIMD (about 1 % of the instances of a 4096 batch went
+// wrong after a change of the code around the barriers; the build before it happened to get away with it).  The
+// wait is therefore written out; tests/test_kernel_resources.py checks the ISA for it at every s_barrier.
+__device__ __forceinline__ void sync_workgroup() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0) (vmcnt, expcnt untouched)
+  __syncthreads();
+}
+__device__ __forceinline__ int sync_workgroup_or(int v) {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  return __syncthreads_or(v);
+}
 #define BMPC_FENCE() asm volatile("" ::: "memory")
 #define BMPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across
 // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
@@ -206,7 +221,7 @@ __device__ __forceinline__ void block_max(float (&v)[NV], float (*red)[NT / 64])
 #pragma unroll
     for (int q = 0; q < NV; ++q) red[q][w] = v[q];
   }
-  __syncthreads();
+  sync_workgroup();
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     unsigned m = __float_as_uint(red[q][0]);
@@ -310,16 +325,18 @@ __device__ __forceinline__ void general_rows(float mu, const float* ey, const fl
   }
 }
 
-template <int H>
-__global__ void __launch_bounds__(Dims<H>::NT, Dims<H>::WPE)
-solve_kernel(const DevParams P, const int B,
+// The solve, as the body of two kernels: solve_kernel<H> (PROF = false: no trace of the diagnostics in the code) and
+// solve_kernel_prof<H> (in-kernel cycle stamps for tools/phase_cycles.py, launched while a profile buffer is set).
+template <int H, bool PROF>
+__device__ __forceinline__ void
+solve_body(const DevParams& P, const int B,
              const float* __restrict__ x_fb, const float* __restrict__ foot,
              const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase,
              const float* __restrict__ x_cmd, const float* __restrict__ mu_in,
              float* __restrict__ controls, float* __restrict__ states,
              int32_t* __restrict__ iters_out, float* __restrict__ resid_out,
              int32_t* __restrict__ status_out, int32_t* __restrict__ nfactor_out,
-             const DebugOut dbg, const WarmArgs warm) {
+             const DebugOut& dbg, const WarmArgs& warm) {
   constexpr int NW = Dims<H>::NW;
   constexpr int HN = Dims<H>::HN;
   constexpr int HH = Dims<H>::HH;
@@ -333,12 +350,12 @@ solve_kernel(const DevParams P, const int B,
 #ifdef BMPC_EMU
   // the emulation poisons the LDS image (all-ones bytes: NaNs) so that a read of an entry nobody wrote shows
   if (threadIdx.x == 0) std::memset(&sm, 0xFF, sizeof(sm));
-  __syncthreads();
+  sync_workgroup();
 #endif
   long long t_start = 0, t_setup = 0, t_blocks = 0, t_sweep = 0, t_mark = 0;
   long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
-#define BMPC_STAMP(k) if (dbg.prof) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
-  if (dbg.prof) t_start = clock64();
+#define BMPC_STAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
+  if constexpr (PROF) t_start = clock64();
   const int l = threadIdx.x;
   const int hf = l & 1;                        // column half of V / Gt, and the foot this lane owns
   const int f = hf;
@@ -428,7 +445,7 @@ solve_kernel(const DevParams P, const int B,
         for (int a = 0; a < 3; ++a) sm.rr[j][ft][a] = fr[3 * ft + a] - xr[3 + a];         // REF:174-175
     }
   }
-  __syncthreads();
+  sync_workgroup();
 #pragma unroll
   for (int q = 0; q < 9; ++q) Pj[q] = 0;
 #pragma unroll 1
@@ -457,7 +474,7 @@ solve_kernel(const DevParams P, const int B,
       for (int i = 0; i < 12; ++i) { sm.u.itv.err[j][i] = e12[i] - xr[i]; sm.s0[j][i] = e12[i]; }
     }
   }
-  __syncthreads();
+  sync_workgroup();
   // Me[i][j2] = dt^2 (P_i - P_j2) Iw_j2 for i > j2: one (i, j2) pair per lane and pass
   for (int idx = l; idx < Dims<H>::NPAIR; idx += NT) {
     int i = (int)((1.f + sqrtf(1.f + 8.f * (float)idx)) * 0.5f);     // invert idx = i (i - 1) / 2 + j2
@@ -474,7 +491,7 @@ solve_kernel(const DevParams P, const int B,
         sm.Me[idx][3 * a + b] = (float)(dt * dt * s);
       }
   }
-  __syncthreads();
+  sync_workgroup();
 
   // ------------------------------------------------------------------ B. wrench-space Hessian row (column half)
   // Half a row of Gt against one component group of the wrench (torque lanes: tau, force lanes: F) over the
@@ -563,7 +580,7 @@ solve_kernel(const DevParams P, const int B,
   }
   gdiag += pair_swap(gdiag);                   // one lane of the pair holds it, the other 0
   if (dbg.assemble_only) return;
-  if (dbg.prof) t_setup = clock64() - t_start;
+  if constexpr (PROF) t_setup = clock64() - t_start;
 
   // ------------------------------------------------------------------ C. constraint data (own foot)
   // General rows of a foot block: G = Gu - mu * [rows 0..3, column 2].  Gu (the mu-free part) is the same
@@ -628,10 +645,10 @@ solve_kernel(const DevParams P, const int B,
 #define VROW(q) Vr[(q) >> 1][(q) & 1]
 
   auto factor = [&]() {
-    if (dbg.prof) t_mark = clock64();
+    if constexpr (PROF) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
     if (valid) sm.rvg[j][f][c] = rvg;
-    __syncthreads();
+    sync_workgroup();
     // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so that
     // none of it is hoisted out of the iteration loop (= holds registers during the iterations)
     int co = c, jo = j;
@@ -690,7 +707,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[b];
     }
-    __syncthreads();
+    sync_workgroup();
     // One 6x6 inverse per step instead of four.  With Y = [W_0^-1; 0] (so W Y = I) and P the D-orthogonal
     // projector I - N Ka^-1 N' D:   L = D^-1 W' F = P Y,   F = (W D^-1 W')^-1 = Y' D L.  In blocks, with
     // B = T' D1 T (Ka = D0 + B) and I - Ka^-1 D0 = Ka^-1 B (no cancellation):
@@ -740,7 +757,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
-    __syncthreads();                          // Ka, B published; D1 consumed
+    sync_workgroup();                          // Ka, B published; D1 consumed
     inv6_row(sm.u.fac.Ka[j], co, ka);           // both lanes of the row, each for itself: no exchange
     if (on0) {
 #pragma unroll
@@ -749,7 +766,7 @@ solve_kernel(const DevParams P, const int B,
     double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
     if (on0) row_times_mat6(ka, sm.u.fac.M2[j], xk);
     if (on1) row_times_mat6(ka, sm.u.fac.M0[j], xk);
-    __syncthreads();                          // B, D0 consumed; Ka^-1 published
+    sync_workgroup();                          // B, D0 consumed; Ka^-1 published
     if (valid) {
       const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
       // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0]
@@ -769,7 +786,7 @@ solve_kernel(const DevParams P, const int B,
         for (int b = 0; b < 6; ++b) sm.u.fac.M0[j][c][b] = w0[b];   // Ka^-1 D0 W_0^-1 rows for L_1
       }
     }
-    __syncthreads();
+    sync_workgroup();
     double fv64[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // row c of F (lane 0)
     if (on0) {
       row_times_mat6(urow, sm.u.fac.M2[j], fv64);     // F = U L_0
@@ -787,7 +804,7 @@ solve_kernel(const DevParams P, const int B,
         sm.KG[1].d[j][c][b][0] = (float)sk[b];
       }
     }
-    __syncthreads();
+    sync_workgroup();
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
       float gr[6];                             // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
 #pragma unroll
@@ -804,7 +821,7 @@ solve_kernel(const DevParams P, const int B,
         sm.LG[f].d[j][c][i][1] = gl;
       }
     }
-    if (dbg.prof) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
+    if constexpr (PROF) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
     // K' row half = Gt row half + F row on the own step, scaled to unit diagonal (S K' S, S = diag(K')^-1/2:
     // every pivot of the sweep is then <= 1, which the pivot-row update below relies on).
     float fv[6];
@@ -837,7 +854,7 @@ solve_kernel(const DevParams P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) VROW(6 * jj + b) = fmaf(mj, fv[b], VROW(6 * jj + b));
     }
-    __syncthreads();
+    sync_workgroup();
     {
       const f2 d2 = {dsc, dsc};
 #pragma unroll
@@ -885,7 +902,7 @@ solve_kernel(const DevParams P, const int B,
         float* nA = sm.piv[par ^ 1];
         par ^= 1;
         const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
-        __syncthreads();
+        sync_workgroup();
         const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
         const float p11 = bB[u + 1];
         const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
@@ -945,7 +962,7 @@ solve_kernel(const DevParams P, const int B,
       pos = posn;
       ws = wsn;
     }
-    if (dbg.prof) t_sweep += clock64() - t_mark;
+    if constexpr (PROF) t_sweep += clock64() - t_mark;
   };
 
   int nfac = 0;
@@ -982,7 +999,7 @@ solve_kernel(const DevParams P, const int B,
   // exact axg, bwl, gbl from x (exchange through LDS); all threads call
   auto refresh = [&]() {
     if (valid) sm.xs[j][f][c] = xo;
-    __syncthreads();
+    sync_workgroup();
     if (valid) {
       RT xblk[2][6], gu[6];
 #pragma unroll
@@ -1016,7 +1033,7 @@ solve_kernel(const DevParams P, const int B,
         sm.u.itv.bwT[c][j] = c3 == 0 ? v3[0] : (c3 == 1 ? v3[1] : v3[2]);
       }
     }
-    __syncthreads();
+    sync_workgroup();
     RT gpart = 0;
     if (valid) {
       // (Gt b)[row] over the own column half in f64: 3 HH doubles of the lane's component group
@@ -1049,7 +1066,7 @@ solve_kernel(const DevParams P, const int B,
     bool ok = pb0 > 0.f && pg0 > 0.f && pb0 < 3.0e38f && pg0 < 3.0e38f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) ok = ok && (fabs(wv[k]) < 1.0e300);
-    ok = __syncthreads_or(ok ? 0 : 1) == 0;    // all of the instance's state or none of it
+    ok = sync_workgroup_or(ok ? 0 : 1) == 0;    // all of the instance's state or none of it
     if (ok) {
       xo = wv[0];
       zb = fmin(fmax(wv[1], (RT)lb), (RT)ub);
@@ -1073,7 +1090,7 @@ solve_kernel(const DevParams P, const int B,
       ++nfac;
       need_factor = false;
     }
-    if (dbg.prof) t_last = clock64();
+    if constexpr (PROF) t_last = clock64();
     // --- P0: row residuals w = y + rho (A x - z); publish them and the gradient
     RT wb = 0;
     if (valid) {
@@ -1089,7 +1106,7 @@ solve_kernel(const DevParams P, const int B,
     rx0 = sm.rx[j][f][c][0]; rx1 = sm.rx[j][f][c][1];
 #pragma unroll
     for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f].d[j][i][c][0];
-    __syncthreads();
+    sync_workgroup();
     BMPC_STAMP(0)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     if (valid) {
@@ -1119,7 +1136,7 @@ solve_kernel(const DevParams P, const int B,
       kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
       lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
     }
-    __syncthreads();
+    sync_workgroup();
     BMPC_STAMP(2)
     // --- P3: beta = L' r (own foot's part, summed over the pair), published scaled
     float rj[2][6];
@@ -1154,7 +1171,7 @@ solve_kernel(const DevParams P, const int B,
       for (int i = 0; i < 6; ++i) ddk = __builtin_elementwise_fma(kg[i], f2{tn[i], tn[i]}, ddk);
       if (f == 1) ddk = -ddk;
     }
-    __syncthreads();
+    sync_workgroup();
     BMPC_STAMP(3)
     // --- P4: gamma = V beta over the own column half, summed over the pair   (Vr holds -S V S)
     float gown;
@@ -1181,7 +1198,7 @@ solve_kernel(const DevParams P, const int B,
                             : &sm.u.itv.gamT[(c < 3 ? 0 : 2) + (j >= HH ? 1 : 0)][(c < 3 ? c : c - 3) * HH + (j >= HH ? j - HH : j)];
       *gdst = gown;
     }
-    __syncthreads();
+    sync_workgroup();
     BMPC_STAMP(4)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;   // residual statistics: only where the stopping test runs
@@ -1375,7 +1392,7 @@ solve_kernel(const DevParams P, const int B,
       if (c == 0 && hf == 0) so[12] = 1.0f;
     }
   }
-  if (dbg.prof && l == 0) {
+  if (PROF && dbg.prof && l == 0) {
     long long* pr = dbg.prof + (size_t)inst * 16;
     pr[0] = t_setup; pr[1] = t_blocks; pr[2] = t_sweep; pr[3] = clock64() - t_start; pr[4] = it; pr[5] = nfac;
 #pragma unroll
@@ -1388,5 +1405,23 @@ solve_kernel(const DevParams P, const int B,
     if (resid_out) { resid_out[2 * inst] = res_p; resid_out[2 * inst + 1] = res_s; }
   }
 }
+
+#define BMPC_SOLVE_ARGS                                                                                            \
+  const DevParams P, const int B, const float* __restrict__ x_fb, const float* __restrict__ foot,                  \
+      const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase, const float* __restrict__ x_cmd,     \
+      const float* __restrict__ mu_in, float* __restrict__ controls, float* __restrict__ states,                   \
+      int32_t* __restrict__ iters_out, float* __restrict__ resid_out, int32_t* __restrict__ status_out,            \
+      int32_t* __restrict__ nfactor_out, const DebugOut dbg, const WarmArgs warm
+template <int H>
+__global__ void __launch_bounds__(Dims<H>::NT, Dims<H>::WPE) solve_kernel(BMPC_SOLVE_ARGS) {
+  solve_body<H, false>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
+                       nfactor_out, dbg, warm);
+}
+template <int H>
+__global__ void __launch_bounds__(Dims<H>::NT, Dims<H>::WPE) solve_kernel_prof(BMPC_SOLVE_ARGS) {
+  solve_body<H, true>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
+                      nfactor_out, dbg, warm);
+}
+#undef BMPC_SOLVE_ARGS
 
 }  // namespace bmpc

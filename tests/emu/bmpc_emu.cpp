@@ -8,9 +8,11 @@
 // is a std::barrier over the workgroup, and the cross-lane operations (pair swap, wave maximum) go through a
 // shared array between two barriers -- which demands what the GPU code must guarantee anyway: every lane of
 // the workgroup reaches every barrier and every cross-lane operation.
+#include <atomic>
 #include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -28,7 +30,12 @@ struct emu_idx { int x; };
 static thread_local emu_idx threadIdx, blockIdx;
 static std::barrier<>* g_bar = nullptr;
 static int g_or[2];
+// byte the LDS image starts from (all-ones = NaNs; BMPC_EMU_POISON tries other leftovers: a result that changes with
+// it reads LDS that nobody wrote)
+static int g_poison = 0xFF;
 static int g_swap[1024];
+static std::atomic<unsigned> g_pair[512];
+static std::barrier<>* g_wbar[16] = {};      // one per wave
 static unsigned g_red[1024];
 
 static inline void __syncthreads() { g_bar->arrive_and_wait(); }
@@ -65,20 +72,33 @@ namespace bmpc {
 static inline double rcp_approx(double x) { return 1.0 / x; }
 static inline float rcp_approx(float x) { return 1.0f / x; }
 static inline float rsq_approx(float x) { return 1.0f / std::sqrt(x); }
+static inline void sync_workgroup() { __syncthreads(); }
+static inline int sync_workgroup_or(int v) { return __syncthreads_or(v); }
+// The cross-lane operations synchronise only the lanes that take part (the pair, the wave), as on the GPU, where a
+// DPP exchange is no barrier: an LDS hand-over that relied on one would be a race there, and is one here (visible
+// to ThreadSanitizer: tests/emu/tsan.sh).
+static inline void pair_sync() {
+  // two-party barrier of lanes (l, l ^ 1): the counter goes 2 k -> 2 k + 2 per rendezvous
+  std::atomic<unsigned>& cnt = g_pair[threadIdx.x >> 1];
+  const unsigned old = cnt.fetch_add(1, std::memory_order_acq_rel);
+  const unsigned target = (old | 1u) + 1u;
+  while (cnt.load(std::memory_order_acquire) < target) std::this_thread::yield();
+}
 static inline int pair_swap_i(int v) {
   g_swap[threadIdx.x] = v;
-  __syncthreads();
+  pair_sync();
   const int r = g_swap[threadIdx.x ^ 1];
-  __syncthreads();
+  pair_sync();
   return r;
 }
 static inline unsigned wave_umax(unsigned v) {          // maximum over the lane's wave (64 consecutive lanes)
+  std::barrier<>& wb = *g_wbar[threadIdx.x >> 6];
   g_red[threadIdx.x] = v;
-  __syncthreads();
+  wb.arrive_and_wait();
   unsigned m = 0;
   const int w0 = threadIdx.x & ~63;
   for (int i = 0; i < 64; ++i) m = g_red[w0 + i] > m ? g_red[w0 + i] : m;
-  __syncthreads();
+  wb.arrive_and_wait();
   return m;
 }
 }  // namespace bmpc
@@ -99,6 +119,9 @@ void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot
   for (int b = 0; b < B; ++b) {
     std::barrier<> bar(NT);
     g_bar = &bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wb;
+    for (int w = 0; w < NT / 64; ++w) { wb.emplace_back(new std::barrier<>(64)); g_wbar[w] = wb.back().get(); }
+    for (int p = 0; p < NT / 2; ++p) g_pair[p].store(0);
     g_or[0] = g_or[1] = 0;
     std::vector<std::thread> th;
     th.reserve(NT);
@@ -149,6 +172,7 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.eps_pri = (float)p->eps_pri; d.eps_dua = (float)p->eps_dua; d.kappa = (float)p->kappa;
   bmpc::DebugOut dbg = {dbg_x_ref, dbg_foot_ref, dbg_Gt, dbg_qt, nullptr, assemble_only};
   bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta, p->warm_adapt_start};
+  if (const char* e = std::getenv("BMPC_EMU_POISON")) g_poison = std::atoi(e);
   switch (p->h) {
     case 10: run_h<10>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
     case 16: run_h<16>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;

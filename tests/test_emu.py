@@ -67,3 +67,23 @@ def test_warm_start_same_optimum_on_cpu():
     assert util.rel_err(o1["controls"].astype(float), ref[None]).max() <= util.REL_TOL
     assert util.rel_err(cold1["controls"].astype(float), ref[None]).max() <= util.REL_TOL
     print("iterations: warm", o1["iters"][0], "cold", cold1["iters"][0])     # fewer on average, not for every instance
+
+
+def test_no_lds_hand_over_without_a_barrier():
+    """The emulation under ThreadSanitizer (tests/emu/tsan.py): lanes synchronise only where the GPU does (workgroup
+    barrier, pair exchange, wave reduction), so an LDS value handed from one lane to another without an s_barrier in
+    between is a data race on the shared-memory image.  The only reports allowed are write/write pairs from ONE source
+    line: the lanes that clone the last row store the same value to the same address as the lane they clone."""
+    from tests.emu import tsan
+    if not os.path.exists(tsan.CLANG):
+        pytest.skip("host clang not available")
+    try:
+        out, err, rc = tsan.run("cfg2_standing_h10", 1)
+    except Exception as e:                      # the sanitizer runtime may be missing from a stripped-down image
+        pytest.skip(f"sanitized build failed: {e}")
+    if "FATAL: ThreadSanitizer" in err:
+        pytest.skip("ThreadSanitizer cannot run in this environment")
+    assert rc == 0 and "status 0" in out, (rc, out, err[-2000:])
+    for acc in tsan.races(err):
+        kinds, where = [a[0] for a in acc], {a[1] for a in acc}
+        assert all("rite" in k for k in kinds) and len(where) == 1 and "?" not in where, acc

@@ -23,7 +23,7 @@ def test_no_spills_and_two_waves_per_simd(tmp_path):
     text = open(out).read()
     seen = {}
     for entry in re.split(r"\n\s+- (?=\.agpr_count:)", text)[1:]:          # one metadata entry per kernel
-        m = re.search(r"\.name:\s+\S*solve_kernelILi(\d+)EE", entry)
+        m = re.search(r"\.name:\s+\S*solve_kernelILi(\d+)EE", entry)       # (not the diagnostics build solve_kernel_prof)
         if m:
             seen[int(m.group(1))] = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\n", entry.split(".wavefront_size")[0])
                                      if k != "offset" and k != "size"}
@@ -35,6 +35,44 @@ def test_no_spills_and_two_waves_per_simd(tmp_path):
         lds = int(meta["group_segment_fixed_size"])
         waves = {10: 2, 16: 3, 20: 4}[h]
         assert 160 * 1024 // lds >= 8 // waves, (h, lds)       # LDS admits the instances the 8 wave slots of a CU can hold
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
+def test_every_barrier_waits_for_the_waves_lds_operations(tmp_path):
+    """An s_barrier that a wave can reach with an LDS store still in flight lets the other waves read the old value.
+    ROCm 7.2's hipcc leaves the `s_waitcnt lgkmcnt(0)` of __syncthreads()' release fence out at the top of the sweep
+    loop (the loop's back edge carries a pending ds_write): on MI355X that showed as results changing from run to
+    run as soon as two waves shared a SIMD.  The kernels therefore write the wait out (bmpc::sync_workgroup); this
+    test reads the ISA of every solve kernel and requires that, walking back from each s_barrier, an
+    `s_waitcnt ... lgkmcnt(0)` comes before any LDS instruction, branch or block label."""
+    import __graft_entry__ as ge
+    out = str(tmp_path / "bmpc.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "--cuda-device-only", "-S", os.path.join(ge.CSRC, "bmpc_capi.hip"), "-o", out] + ge.KERNEL_FLAGS,
+                          cwd=ge.CSRC, stderr=subprocess.DEVNULL)
+    lines = open(out).read().splitlines()
+    checked = 0
+    for i, ln in enumerate(lines):
+        m = re.match(r"(_ZN4bmpc\d+solve_kernel\w*ILi\d+EE\S*):", ln)
+        if not m:
+            continue
+        end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        body = [x.split(";")[0].strip() for x in lines[i + 1:end]]
+        body = [x for x in body if x and (not x.startswith(".") or re.match(r"\.LBB\d+_\d+:", x))]
+        for k, x in enumerate(body):
+            if not x.startswith("s_barrier"):
+                continue
+            checked += 1
+            j = k - 1
+            while True:
+                assert j >= 0, (m.group(1), "barrier at the top of the kernel")
+                y = body[j]
+                if y.startswith("s_waitcnt") and "lgkmcnt(0)" in y:
+                    break
+                assert not (y.startswith("ds_") or y.startswith(".LBB") or y.startswith("s_cbranch") or y.startswith("s_branch")), \
+                    (m.group(1), "s_barrier reachable without lgkmcnt(0)", body[max(0, j - 3):k + 1])
+                j -= 1
+    assert checked >= 6 * 20, checked           # 3 horizons x {solve_kernel, solve_kernel_prof}
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
