@@ -606,3 +606,36 @@ def test_reference_generators_dropin():
     d = util.load("cfg4_walking_h10")
     xr, fr = bm.reference_trajectories_batch(d["x_fb"], d["t"], d["foot"], d["contact"], mpc=mpc, x_cmd=d["x_cmd"])
     assert np.abs(xr - d["x_ref"]).max() < 1e-6 and np.abs(fr - d["foot_ref"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 2048), (5, 2048)])
+def test_results_do_not_change_from_run_to_run(cfg, B):
+    """The same batch solved six times gives bit-identical outputs, at a size that puts two waves on every SIMD (that is
+    where a workgroup barrier reached with an LDS store in flight showed: ~1 % of the instances of a 4096 batch changed
+    between runs, some to NaN, before the wait in front of every barrier was written out -- bmpc::sync_workgroup), and
+    every instance converges in every run."""
+    import torch
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import synth
+    c = synth.CONFIGS[cfg]
+    s = synth.synth_batch(B, c["h"], c["seed"], gait=c["gait"], **c["kw"])
+    mpc = bm.MPC()
+    mpc.h = c["h"]
+    solver = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    dev = torch.device("cuda:0")
+    t = {k: (None if s[k] is None else torch.from_numpy(np.ascontiguousarray(
+        s[k].astype(np.float32) if s[k].dtype == np.float64 else s[k])).to(dev)) for k in ("x_fb", "foot", "contact", "phase", "x_cmd", "mu")}
+    ref = None
+    for rep in range(6):
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        states = torch.empty((B, c["h"], 13), dtype=torch.float32, device=dev)
+        controls, _ = solver.solve_device(t["x_fb"], t["foot"], t["contact"], t["phase"], t["x_cmd"], t["mu"], states=states,
+                                          status=status)
+        torch.cuda.synchronize()
+        out = (controls.cpu().numpy(), states.cpu().numpy())
+        assert (status.cpu().numpy() == 0).all(), (rep, np.flatnonzero(status.cpu().numpy()))
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), (rep, np.flatnonzero((a != b).any(axis=(1, 2)))[:10])
