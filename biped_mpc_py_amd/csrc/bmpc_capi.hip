@@ -204,9 +204,18 @@ int bmpc_default_params(bmpc_params* p, int h) {
   for (int i = 0; i < 3; ++i) { p->f_max[i] = 500; p->f_min[i] = 0; } // REF:45-46
   p->tau_max[0] = 0; p->tau_max[1] = 67; p->tau_max[2] = 33.5;        // REF:47
   for (int i = 0; i < 3; ++i) p->tau_min[i] = -p->tau_max[i];         // REF:48
-  p->rho = 0.03; p->rho_eq_scale = 1e3; p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 20.0;
+  p->rho = h < 20 ? 0.03 : 0.045;          // (h = 20: -2.5 % kernel time, fewer late re-classifications)
+  p->rho_eq_scale = h < 20 ? 1e3 : 1e3 * 0.03 / 0.045;               // rho_eq = 30 for every horizon
+  p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 20.0;
   p->alpha = 1.6; p->eps_pri = 1e-7; p->eps_dua = 1e-7;
-  p->max_iter = 400; p->check_every = 5; p->adapt_start = 10; p->adapt_every = 10; p->max_refactor = 24;
+  p->max_iter = h <= 12 ? 400 : 600;       // (worst seen in the soaks: 240 at h = 10, 315 at h = 16 / 20 with the periods below)
+  p->check_every = 5; p->max_refactor = 24;
+  // Re-classification period ~ (cost of a factorisation) / (cost of an iteration): 10.6 at h = 10, 15.6 at h = 16,
+  // 21.5 at h = 20 (profiles/r02_cfg*_phase_cycles.txt).  Measured on MI355X (build_tmp-style A/B, round 2):
+  // h = 16: period 20 from iteration 10 is 8 % faster than 10 / 10 (4.3 instead of 5.6 factorisations, 68 instead of
+  // 53 iterations), h = 20: 20 / 20 is 12 % faster (4.8 instead of 6.8, 88 instead of 66); h = 10 is best at 10 / 10.
+  p->adapt_every = h <= 12 ? 10 : 20;
+  p->adapt_start = h < 20 ? 10 : 20;
   p->warm_adapt_start = 5;                                            // (tools/warm_sweep.py)
   p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
   p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31

@@ -68,7 +68,7 @@ typedef struct bmpc_params {
   double f_max[3], f_min[3];     /* REF:45-46 */
   double tau_max[3], tau_min[3]; /* REF:47-48 */
   /* solver (ADMM with active-set adaptive penalties) */
-  double rho;                /* initial penalty on every row */
+  double rho;                /* initial penalty on every row (default 0.03; 0.045 at h = 20) */
   double rho_eq_scale;       /* multiplier for rows with l == u (pinned variables) */
   double rho_lo;             /* floor of the per-row penalties */
   double rho_hi_f;           /* ceiling for force-like rows (force box, friction) */
@@ -81,8 +81,9 @@ typedef struct bmpc_params {
   double eps_pri, eps_dua;   /* relative stopping tolerances */
   int32_t max_iter;
   int32_t check_every;       /* stopping test period */
-  int32_t adapt_start;       /* first penalty re-classification */
-  int32_t adapt_every;       /* re-classification period (0 = never) */
+  int32_t adapt_start;       /* first penalty re-classification (default 10; 20 at h = 20) */
+  int32_t adapt_every;       /* re-classification period (0 = never; default 10 at h = 10, 20 at h = 16, 20: the
+                                period follows the cost of a factorisation relative to an iteration) */
   int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached) */
   int32_t warm_adapt_start;  /* first re-classification of a warm-started solve (bmpc_set_warm_start); 0 = adapt_start */
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
