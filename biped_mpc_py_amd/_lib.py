@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -19,7 +19,7 @@ EXPORTS = (
     "bmpc_foot_position_world", "bmpc_foot_position_world_device",
     "bmpc_low_level_control", "bmpc_low_level_control_device",
     "bmpc_gait_default", "bmpc_contact_sequence", "bmpc_contact_sequence_device",
-    "bmpc_set_warm_start", "bmpc_reset_warm_start", "bmpc_rollout_device",
+    "bmpc_set_warm_start", "bmpc_reset_warm_start", "bmpc_rollout_device", "bmpc_set_dispatch_order",
 )
 
 
@@ -112,6 +112,7 @@ def load():
     lib.bmpc_contact_sequence_device.argtypes = [vp, ip, vp, C.POINTER(CGait), vp, vp, vp]
     lib.bmpc_set_warm_start.argtypes = [vp, ip, ip, C.c_double]
     lib.bmpc_reset_warm_start.argtypes = [vp]
+    lib.bmpc_set_dispatch_order.argtypes = [vp, vp, ip]
     lib.bmpc_rollout_device.argtypes = [vp, ip, ip, vp, vp, vp, C.POINTER(CGait), vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

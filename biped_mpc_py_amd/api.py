@@ -240,6 +240,20 @@ class BatchSolver:
     def reset_warm_start(self):
         _lib.check(self._lib.bmpc_reset_warm_start(self._h))
 
+    def set_dispatch_order(self, order=None, longest_first_rollouts=True):
+        """`bmpc_set_dispatch_order`: `order` is None or an int32 CUDA(HIP) tensor holding a permutation of 0 .. B-1
+        (workgroup g solves instance order[g]; keep the tensor alive while it is set); `longest_first_rollouts`:
+        roll-outs dispatch each period's instances by descending iteration count of the period before.  Results never
+        depend on the order, only the time a batch takes."""
+        import torch
+        ptr = None
+        if order is not None:
+            if not (isinstance(order, torch.Tensor) and order.is_cuda and order.dtype == torch.int32 and order.is_contiguous()):
+                raise ValueError("order must be a contiguous int32 tensor on the solver's device")
+            ptr = order.data_ptr()
+        self._order_keepalive = order
+        _lib.check(self._lib.bmpc_set_dispatch_order(self._h, ptr, 1 if longest_first_rollouts else 0))
+
     def rollout_device(self, x_fb, foot, t, steps, x_cmd=None, mu=None, period=None, offset=None, duty=None,
                        want_iters=True, stream=None):
         """`steps` closed-loop control periods on device tensors (`bmpc_rollout_device`): x_fb (B,12) float32 and

@@ -116,7 +116,9 @@ struct bmpc_handle_s {
   // roll-out scratch (bmpc_rollout_device)
   DevBuf<float> ro_controls, ro_states;
   DevBuf<uint8_t> ro_contact;
-  DevBuf<int32_t> ro_phase, ro_iters, ro_status;
+  DevBuf<int32_t> ro_phase, ro_iters, ro_status, ro_order;
+  const int32_t* order = nullptr;   // dispatch order of the next solves (bmpc_set_dispatch_order; roll-outs set their own)
+  bool longest_first = true;        // roll-outs order each period's solve by the previous period's iteration counts
 };
 
 namespace {
@@ -127,7 +129,7 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
              hipStream_t st) {
   constexpr int NT = bmpc::Dims<H>::NT;
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0};
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : hd->order};
   if (hd->warm_on && !dbg.assemble_only) {
     const size_t need = (size_t)B * NT * 6;
     if (need > hd->warm.n) hd->warm_valid = false;          // growing the buffer loses the stored state
@@ -546,19 +548,35 @@ int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const floa
   HIP_TRY(h->ro_iters.ensure(n)); HIP_TRY(h->ro_status.ensure(n));
   hipStream_t st = pick_stream(h, stream);
   if (status_any) HIP_TRY(hipMemsetAsync(status_any, 0, n * sizeof(int32_t), st));
-  for (int s = 0; s < steps; ++s) {
+  const int32_t* user_order = h->order;
+  if (h->longest_first && !user_order) HIP_TRY(h->ro_order.ensure(n));
+  int rc = BMPC_OK;
+  for (int s = 0; s < steps && rc == BMPC_OK; ++s) {
     // t -> (phase, contact) -> solve -> x_fb <- states[:, 0], t += dt: three launches on one stream, no host arithmetic
-    int rc = bmpc_contact_sequence_device(h, B, t, gait, h->ro_phase.p, h->ro_contact.p, st);
-    if (rc != BMPC_OK) return rc;
+    // (plus, from the second period on, the dispatch order: the instances that iterated longest last period go first)
+    rc = bmpc_contact_sequence_device(h, B, t, gait, h->ro_phase.p, h->ro_contact.p, st);
+    if (rc != BMPC_OK) break;
+    if (h->longest_first && !user_order && s > 0) {
+      hipLaunchKernelGGL(bmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, st, B, h->ro_iters.p, h->ro_order.p);
+      h->order = h->ro_order.p;
+    }
     rc = bmpc_solve_batch_device(h, B, x_fb, foot, h->ro_contact.p, h->ro_phase.p, x_cmd, mu, h->ro_controls.p,
                                  h->ro_states.p, h->ro_iters.p, nullptr, h->ro_status.p, nullptr, st);
-    if (rc != BMPC_OK) return rc;
+    if (rc != BMPC_OK) break;
     hipLaunchKernelGGL(bmpc::rollout_feedback_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, (int)H, h->params.dt,
                        h->ro_states.p, h->ro_controls.p, h->ro_iters.p, h->ro_status.p, x_fb, t,
                        u0_traj ? u0_traj + (size_t)s * n * 12 : nullptr, x_traj ? x_traj + (size_t)s * n * 12 : nullptr,
                        iters_traj ? iters_traj + (size_t)s * n : nullptr, status_any);
-    HIP_TRY(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) rc = fail(BMPC_ERR_HIP, "roll-out launch failed");
   }
+  h->order = user_order;
+  return rc;
+}
+
+int bmpc_set_dispatch_order(bmpc_handle h, const int32_t* order_dev, int longest_first_rollouts) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  h->order = order_dev;
+  h->longest_first = longest_first_rollouts != 0;
   return BMPC_OK;
 }
 

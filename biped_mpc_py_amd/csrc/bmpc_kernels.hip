@@ -100,6 +100,9 @@ struct WarmArgs {
   int shift;                 // the stored horizon is advanced by this many steps on load (0: same schedule phase)
   float theta;               // penalties restart at rho0 (rho_stored / rho0)^theta: 1 keeps them, 0 forgets them
   int adapt_start;           // first penalty re-classification of a warm-started solve (<= 0: as for a cold one)
+  // dispatch order or null: workgroup g solves instance order[g] (a permutation of 0 .. B-1).  Workgroups start in
+  // index order, so listing the instances expected to take longest first keeps the tail of a batch short.
+  const int32_t* order;
 };
 
 template <int H>
@@ -345,8 +348,8 @@ solve_body(const DevParams& P, const int B,
   constexpr int NT = Dims<H>::NT;
   __shared__ Smem<H> sm;
 
-  const int inst = blockIdx.x;
-  if (inst >= B) return;
+  if ((int)blockIdx.x >= B) return;
+  const int inst = warm.order ? warm.order[blockIdx.x] : (int)blockIdx.x;
 #ifdef BMPC_EMU
   // the emulation poisons the LDS image (all-ones bytes: NaNs) so that a read of an entry nobody wrote shows
   if (threadIdx.x == 0) std::memset(&sm, 0xFF, sizeof(sm));

@@ -220,4 +220,28 @@ __global__ void rollout_feedback_kernel(int B, int h, double dt, const float* __
   if (status_any) status_any[b] |= status[b];
 }
 
+// Dispatch order for the next solve of a batch whose previous solve took iters[b] iterations: instances sorted by
+// descending iteration count (counting sort over iteration buckets, ONE workgroup; the order inside a bucket is
+// whatever the atomics give -- the results of a solve do not depend on the order, only its duration does).
+constexpr int ORDER_BINS = 512;
+__global__ void __launch_bounds__(1024) dispatch_order_kernel(int B, const int32_t* __restrict__ iters, int32_t* __restrict__ order) {
+  __shared__ int bin[ORDER_BINS];
+  for (int k = threadIdx.x; k < ORDER_BINS; k += blockDim.x) bin[k] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int key = min(max(iters[b], 0), ORDER_BINS - 1);
+    atomicAdd(&bin[key], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                       // start of every bucket, longest first (512 additions: microseconds)
+    int acc = 0;
+    for (int k = ORDER_BINS - 1; k >= 0; --k) { const int n = bin[k]; bin[k] = acc; acc += n; }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int key = min(max(iters[b], 0), ORDER_BINS - 1);
+    order[atomicAdd(&bin[key], 1)] = b;
+  }
+}
+
 }  // namespace bmpc

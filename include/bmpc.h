@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 4
+#define BMPC_ABI_VERSION 5
 
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
@@ -213,12 +213,22 @@ int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bm
  *   x_cmd [B][12] or NULL, mu [B][h][2] or NULL (constant over the roll-out);
  *   u0_traj [steps][B][12], x_traj [steps][B][12] (state after each period), iters_traj [steps][B],
  *   status_any [B] (OR of the per-period status values): each may be NULL.
+ *
+ * bmpc_set_dispatch_order: workgroups start in index order and an instance's duration varies (35-105 iterations at
+ * h = 10), so the last instances of a batch decide when it ends: the same 4096 instances take 15 % less time when the
+ * longest are dispatched first (tools/order_probe.py).  The duration cannot be predicted from the inputs, but in a
+ * closed loop the previous period's iteration count predicts it: with longest_first_rollouts != 0 (default)
+ * bmpc_rollout_device sorts every period's dispatch by the iteration counts of the period before (one small
+ * kernel).  order_dev, if non-NULL, is a DEVICE permutation of 0 .. B-1 used by every later solve of this handle
+ * (workgroup g solves instance order_dev[g]) and takes precedence; it must stay valid until replaced.  The results
+ * never depend on the order.
  */
 int bmpc_set_warm_start(bmpc_handle h, int enable, int shift, double theta);
 int bmpc_reset_warm_start(bmpc_handle h);
 int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const float* foot, double* t,
                         const bmpc_gait* gait, const float* x_cmd, const float* mu,
                         float* u0_traj, float* x_traj, int32_t* iters_traj, int32_t* status_any, void* stream);
+int bmpc_set_dispatch_order(bmpc_handle h, const int32_t* order_dev, int longest_first_rollouts);
 
 /* Diagnostics: when device_buf (DEVICE pointer, [max_batch][16] int64) is non-NULL every later solve
  * writes per-instance shader-clock stamps {setup, block algebra, dense sweeps, total, iters,
