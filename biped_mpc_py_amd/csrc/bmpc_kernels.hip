@@ -57,6 +57,14 @@ __device__ __forceinline__ void sync_workgroup() {
   __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0) (vmcnt, expcnt untouched)
   __syncthreads();
 }
+// Exchange between lanes of ONE wave through LDS: a wave's DS operations execute in order, so the hand-over needs
+// no s_barrier and no wait; the fences only keep the compiler from reordering the accesses.
+#define BMPC_WAVE_SYNC()                                        \
+  do {                                                          \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+    __builtin_amdgcn_wave_barrier();                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+  } while (0)
 __device__ __forceinline__ int sync_workgroup_or(int v) {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   return __syncthreads_or(v);
@@ -111,8 +119,15 @@ struct Dims {
   static constexpr int NW = 6 * H;                       // wrench rows
   static constexpr int HN = NW / 2;                      // columns of V a lane holds (= 3 H)
   static constexpr int HH = H / 2;                       // steps per column half
-  static constexpr int NT = ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
+  // Lane map.  Where five steps (30 rows, 60 lanes) fill a wave -- h = 10: 2 waves, h = 20: 4 -- the steps never straddle
+  // waves (SW = 5 steps per wave, the last 4 lanes of every wave clone the wave's last row), and everything exchanged
+  // between the lanes of ONE step (the 6x6 block algebra, the control-space residual, beta = L'r) stays inside a
+  // wave: no s_barrier, only the wave's own LDS ordering.  h = 16 (16 steps: 3 waves of 32 rows) keeps rows dense.
+  static constexpr int SW = (H % 5 == 0) ? 5 : 0;
+  static constexpr bool WL = SW > 0;                      // steps are wave-local
+  static constexpr int NT = WL ? 64 * (H / 5) : ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
   static constexpr int NWV = NT / 64;
+  __host__ __device__ static constexpr int lane_of(int row, int f) { return WL ? 64 * (row / 30) + 2 * (row % 30) + f : 2 * row + f; }
   // Waves per SIMD the register allocation aims at.  An instance is a latency-bound chain of LDS exchanges, so a
   // CU's throughput is (instances in flight) / (latency of one); two per SIMD = 4 instances per CU at h = 10.
   // Three per SIMD (<= 168 registers) was measured with the DPP-broadcast variant of this kernel (DESIGN.md
@@ -362,13 +377,18 @@ solve_body(const DevParams& P, const int B,
   const int l = threadIdx.x;
   const int hf = l & 1;                        // column half of V / Gt, and the foot this lane owns
   const int f = hf;
-  // The lanes past the last row (8 at h = 10, 16 at h = 20) CLONE the last row: same indices, same data, same
+  // The lanes past the last row (of the wave: 4 per wave at h = 10, 20; of the workgroup at h = 16) CLONE the last row: same indices, same data, same
   // arithmetic, so their LDS writes repeat the real lane's values at the real lane's addresses and nothing has
   // to be predicated (every `if (lane is real)` would be an exec-mask branch, and the code sinking across such
   // branches is what blew up the sweep's register pressure); only their global stores are suppressed.
-  const bool real = (l >> 1) < NW;
-  const int row = real ? (l >> 1) : NW - 1;
+  const bool real = Dims<H>::WL ? ((l & 63) >> 1) < 30 : (l >> 1) < NW;
+  const int row = Dims<H>::WL ? 30 * (l >> 6) + (real ? (l & 63) >> 1 : 29) : (real ? (l >> 1) : NW - 1);
   constexpr bool valid = true;
+  // synchronisation of the lanes of one step (block algebra, control-space residual, beta): wave-local where the
+  // lane map keeps a step inside a wave, a workgroup barrier otherwise
+  auto sync_step = [&]() {
+    if constexpr (Dims<H>::WL) { BMPC_WAVE_SYNC(); } else { sync_workgroup(); }
+  };
   const int j = row / 6;
   const int c = row % 6;
   const int jb = hf * HH;                      // first step of this lane's column half
@@ -710,7 +730,7 @@ solve_body(const DevParams& P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[b];
     }
-    sync_workgroup();
+    sync_step();
     // One 6x6 inverse per step instead of four.  With Y = [W_0^-1; 0] (so W Y = I) and P the D-orthogonal
     // projector I - N Ka^-1 N' D:   L = D^-1 W' F = P Y,   F = (W D^-1 W')^-1 = Y' D L.  In blocks, with
     // B = T' D1 T (Ka = D0 + B) and I - Ka^-1 D0 = Ka^-1 B (no cancellation):
@@ -760,7 +780,7 @@ solve_body(const DevParams& P, const int B,
 #pragma unroll
       for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
-    sync_workgroup();                          // Ka, B published; D1 consumed
+    sync_step();                          // Ka, B published; D1 consumed
     inv6_row(sm.u.fac.Ka[j], co, ka);           // both lanes of the row, each for itself: no exchange
     if (on0) {
 #pragma unroll
@@ -769,7 +789,7 @@ solve_body(const DevParams& P, const int B,
     double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
     if (on0) row_times_mat6(ka, sm.u.fac.M2[j], xk);
     if (on1) row_times_mat6(ka, sm.u.fac.M0[j], xk);
-    sync_workgroup();                          // B, D0 consumed; Ka^-1 published
+    sync_step();                          // B, D0 consumed; Ka^-1 published
     if (valid) {
       const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
       // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0]
@@ -789,7 +809,7 @@ solve_body(const DevParams& P, const int B,
         for (int b = 0; b < 6; ++b) sm.u.fac.M0[j][c][b] = w0[b];   // Ka^-1 D0 W_0^-1 rows for L_1
       }
     }
-    sync_workgroup();
+    sync_step();
     double fv64[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // row c of F (lane 0)
     if (on0) {
       row_times_mat6(urow, sm.u.fac.M2[j], fv64);     // F = U L_0
@@ -807,7 +827,7 @@ solve_body(const DevParams& P, const int B,
         sm.KG[1].d[j][c][b][0] = (float)sk[b];
       }
     }
-    sync_workgroup();
+    sync_step();
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
       float gr[6];                             // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
 #pragma unroll
@@ -1002,7 +1022,7 @@ solve_body(const DevParams& P, const int B,
   // exact axg, bwl, gbl from x (exchange through LDS); all threads call
   auto refresh = [&]() {
     if (valid) sm.xs[j][f][c] = xo;
-    sync_workgroup();
+    sync_step();
     if (valid) {
       RT xblk[2][6], gu[6];
 #pragma unroll
@@ -1061,7 +1081,7 @@ solve_body(const DevParams& P, const int B,
     // finite (a failed solve) is ignored as a whole.
     int js = j + warm.shift;
     js = js > H - 1 ? H - 1 : js;
-    const double* src = warm.buf + ((size_t)inst * NT + (2 * (6 * js + c) + f)) * 6;
+    const double* src = warm.buf + ((size_t)inst * NT + Dims<H>::lane_of(6 * js + c, f)) * 6;
     double wv[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) wv[k] = src[k];
@@ -1109,7 +1129,7 @@ solve_body(const DevParams& P, const int B,
     rx0 = sm.rx[j][f][c][0]; rx1 = sm.rx[j][f][c][1];
 #pragma unroll
     for (int i = 0; i < 6; ++i) lcol[i] = sm.LG[f].d[j][i][c][0];
-    sync_workgroup();
+    sync_step();
     BMPC_STAMP(0)
     // --- P2: KKT residual in control space r = W' gb + 2R x + A' w   (small at convergence)
     if (valid) {
@@ -1139,7 +1159,7 @@ solve_body(const DevParams& P, const int B,
       kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
       lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
     }
-    sync_workgroup();
+    sync_step();
     BMPC_STAMP(2)
     // --- P3: beta = L' r (own foot's part, summed over the pair), published scaled
     float rj[2][6];

@@ -21,6 +21,7 @@
 #define BMPC_EMU 1
 #define __global__
 #define __device__
+#define __host__
 #define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
@@ -102,6 +103,7 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
   return m;
 }
 }  // namespace bmpc
+#define BMPC_WAVE_SYNC() g_wbar[threadIdx.x >> 6]->arrive_and_wait()
 #define BMPC_FENCE() do { } while (0)
 #define BMPC_OPAQUE(x) do { } while (0)
 #define BMPC_SCHED_BARRIER() do { } while (0)
