@@ -123,11 +123,13 @@ struct Dims {
   // waves (SW = 5 steps per wave, the last 4 lanes of every wave clone the wave's last row), and everything exchanged
   // between the lanes of ONE step (the 6x6 block algebra, the control-space residual, beta = L'r) stays inside a
   // wave: no s_barrier, only the wave's own LDS ordering.  h = 16 (16 steps: 3 waves of 32 rows) keeps rows dense.
+  // (four steps per wave at h = 16 -- 4 waves instead of 3, a quarter of the lanes clones -- measured 8 % slower)
   static constexpr int SW = (H % 5 == 0) ? 5 : 0;
   static constexpr bool WL = SW > 0;                      // steps are wave-local
-  static constexpr int NT = WL ? 64 * (H / 5) : ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
+  static constexpr int RW = 6 * SW;                       // rows per wave
+  static constexpr int NT = WL ? 64 * (H / SW) : ((2 * NW + 63) / 64) * 64;   // threads per workgroup (whole waves)
   static constexpr int NWV = NT / 64;
-  __host__ __device__ static constexpr int lane_of(int row, int f) { return WL ? 64 * (row / 30) + 2 * (row % 30) + f : 2 * row + f; }
+  __host__ __device__ static constexpr int lane_of(int row, int f) { return WL ? 64 * (row / RW) + 2 * (row % RW) + f : 2 * row + f; }
   // Waves per SIMD the register allocation aims at.  An instance is a latency-bound chain of LDS exchanges, so a
   // CU's throughput is (instances in flight) / (latency of one); two per SIMD = 4 instances per CU at h = 10.
   // Three per SIMD (<= 168 registers) was measured with the DPP-broadcast variant of this kernel (DESIGN.md
@@ -381,8 +383,8 @@ solve_body(const DevParams& P, const int B,
   // arithmetic, so their LDS writes repeat the real lane's values at the real lane's addresses and nothing has
   // to be predicated (every `if (lane is real)` would be an exec-mask branch, and the code sinking across such
   // branches is what blew up the sweep's register pressure); only their global stores are suppressed.
-  const bool real = Dims<H>::WL ? ((l & 63) >> 1) < 30 : (l >> 1) < NW;
-  const int row = Dims<H>::WL ? 30 * (l >> 6) + (real ? (l & 63) >> 1 : 29) : (real ? (l >> 1) : NW - 1);
+  const bool real = Dims<H>::WL ? ((l & 63) >> 1) < Dims<H>::RW : (l >> 1) < NW;
+  const int row = Dims<H>::WL ? Dims<H>::RW * (l >> 6) + (real ? (l & 63) >> 1 : Dims<H>::RW - 1) : (real ? (l >> 1) : NW - 1);
   constexpr bool valid = true;
   // synchronisation of the lanes of one step (block algebra, control-space residual, beta): wave-local where the
   // lane map keeps a step inside a wave, a workgroup barrier otherwise
