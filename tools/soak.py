@@ -1,11 +1,16 @@
 """Convergence soak (GPU box): random batches of the four BASELINE config shapes over a range of seeds; prints the
-instances that did not converge and the worst iteration count.  python tools/soak.py [seed_lo seed_hi]"""
+instances that did not converge and the worst iteration count.  python tools/soak.py [seed_lo seed_hi [long]]
+("long": four more shapes of the long horizons -- h = 16 walking / mixed, h = 20 walking / standing with per-step
+friction -- 16384 instances per seed each)"""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import biped_mpc_py_amd as bm
 from tests import util
 tot=0; bad=0; worst=0
-for h, gait, kw in ((10,'mixed',dict(vx_cmd=True)), (10,'standing',{}), (16,'walking',dict(vx_cmd=True)), (20,'walking',dict(vx_cmd=True, per_step_mu=True))):
+SHAPES = ((10,'mixed',dict(vx_cmd=True)), (10,'standing',{}), (16,'walking',dict(vx_cmd=True)), (20,'walking',dict(vx_cmd=True, per_step_mu=True)))
+if len(sys.argv) > 3 and sys.argv[3] == "long":
+    SHAPES = ((16,'walking',dict(vx_cmd=True)), (20,'walking',dict(vx_cmd=True, per_step_mu=True)), (16,'mixed',dict(vx_cmd=True)), (20,'standing',dict(per_step_mu=True)))
+for h, gait, kw in SHAPES:
     mpc=bm.MPC(); mpc.h=h
     B=65536 if h==10 else 16384
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 500, int(sys.argv[2]) if len(sys.argv) > 2 else 540):
