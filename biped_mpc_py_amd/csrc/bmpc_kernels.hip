@@ -69,6 +69,9 @@ __device__ __forceinline__ int sync_workgroup_or(int v) {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   return __syncthreads_or(v);
 }
+// s_waitcnt lgkmcnt(0): used at the back edges of the two hot loops, so that the compiler's bookkeeping of LDS
+// operations in flight never has to be right across a back edge (it was not, at the sweep loop: sync_workgroup above)
+#define BMPC_DRAIN_LDS() __builtin_amdgcn_s_waitcnt(0xc07f)
 #define BMPC_FENCE() asm volatile("" ::: "memory")
 #define BMPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across
 // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
@@ -986,6 +989,7 @@ solve_body(const DevParams& P, const int B,
       }
       pos = posn;
       ws = wsn;
+      BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
     }
     if constexpr (PROF) t_sweep += clock64() - t_mark;
   };
@@ -1366,6 +1370,7 @@ solve_body(const DevParams& P, const int B,
       }
     }
     BMPC_STAMP(6)
+    BMPC_DRAIN_LDS();                           // nothing in flight across the back edge (see sync_workgroup)
   }
   if (valid) sm.xs[j][f][c] = xo;              // for the state roll-out below
   if (warm.buf && warm.store) {

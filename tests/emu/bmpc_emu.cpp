@@ -104,6 +104,7 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
 }
 }  // namespace bmpc
 #define BMPC_WAVE_SYNC() g_wbar[threadIdx.x >> 6]->arrive_and_wait()
+#define BMPC_DRAIN_LDS() do { } while (0)
 #define BMPC_FENCE() do { } while (0)
 #define BMPC_OPAQUE(x) do { } while (0)
 #define BMPC_SCHED_BARRIER() do { } while (0)
