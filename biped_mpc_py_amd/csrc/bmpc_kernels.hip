@@ -13,9 +13,10 @@
 //   solve            the unique minimiser REF:297 asks cvxopt for, by ADMM with active-set adaptive
 //                    penalties; unpack controls / states (REF:300-304)
 //
-// Thread map: TWO lanes per wrench row.  Lane l  <->  (row = l / 2, half hf = l % 2), row = (step j = row / 6,
-// component c = row % 6).  The two lanes of a row are neighbours, so they exchange through DPP (no LDS, no
-// barrier).  Between them they split
+// Thread map: TWO lanes per wrench row, (row, half hf = l % 2), row = (step j = row / 6, component c = row % 6); rows are
+// dense over the lanes at h = 16 (row = l / 2), and at h = 10 / 20 five whole steps (30 rows, 60 lanes) fill a wave, so
+// that a step never straddles waves and what its lanes exchange needs no s_barrier (Dims<H>::WL).  The two lanes of a
+// row are neighbours, so they exchange through DPP (no LDS, no barrier).  Between them they split
 //   * the row of V = (Gt + F)^-1 and of Gt by COLUMN halves: lane hf holds the columns of steps
 //     [hf H/2, (hf + 1) H/2) -- half the sweep, half the mat-vecs, half the registers each,
 //   * the per-step control-space work by FOOT: lane hf owns control variable c of foot hf at step j
