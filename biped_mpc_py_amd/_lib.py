@@ -8,11 +8,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
-    "bmpc_abi_version", "bmpc_last_error", "bmpc_supported_horizon", "bmpc_default_params",
+    "bmpc_abi_version", "bmpc_last_error", "bmpc_supported_horizon", "bmpc_supported_horizon_path", "bmpc_solver_path",
+    "bmpc_effective_penalties",
+    "bmpc_default_params",
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
     "bmpc_solve_batch", "bmpc_solve_batch_device", "bmpc_synchronize",
     "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
@@ -49,6 +51,7 @@ class CParams(C.Structure):
         ("eps_pri", C.c_double), ("eps_dua", C.c_double),
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
         ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("warm_adapt_start", C.c_int32),
+        ("path", C.c_int32), ("penalty_mode", C.c_int32),
         ("kp", C.c_double * 9), ("kd", C.c_double * 9), ("swingHeight", C.c_double), ("hip_offset", C.c_double * 3),
     ]
 
@@ -91,6 +94,9 @@ def load():
     lib.bmpc_abi_version.restype = ip
     lib.bmpc_last_error.restype = C.c_char_p
     lib.bmpc_supported_horizon.argtypes = [ip]
+    lib.bmpc_supported_horizon_path.argtypes = [ip, ip]
+    lib.bmpc_solver_path.argtypes = [vp]
+    lib.bmpc_effective_penalties.argtypes = [C.POINTER(CParams), C.POINTER(C.c_double)]
     lib.bmpc_default_params.argtypes = [C.POINTER(CParams), ip]
     lib.bmpc_create.argtypes = [C.POINTER(vp), C.POINTER(CParams), ip, ip]
     lib.bmpc_destroy.argtypes = [vp]

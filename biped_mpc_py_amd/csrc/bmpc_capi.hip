@@ -2,6 +2,7 @@
 // There is deliberately no CPU path here: without a HIP device every entry point that would
 // compute returns BMPC_ERR_NO_DEVICE.
 #include "bmpc_kernels.hip"
+#include "bmpc_stage.hip"
 #include "bmpc_lowlevel.hip"
 
 #include <cmath>
@@ -41,8 +42,49 @@ bool inv3(const double* a, double* o) {
   return true;
 }
 
+bool dense_horizon(int h) { return h >= 8 && h <= 20 && h % 2 == 0; }
+bool stage_horizon(int h) { return h >= 8 && h <= 40 && h % 2 == 0; }
+// the kernel family that solves horizon h when the caller asks for `path`; 0 if there is none
+int resolve_path(int h, int path) {
+  if (path == BMPC_PATH_DENSE) return dense_horizon(h) ? BMPC_PATH_DENSE : 0;
+  if (path == BMPC_PATH_STAGE) return stage_horizon(h) ? BMPC_PATH_STAGE : 0;
+  if (path != BMPC_PATH_AUTO) return 0;
+  if (dense_horizon(h)) return BMPC_PATH_DENSE;
+  return stage_horizon(h) ? BMPC_PATH_STAGE : 0;
+}
+
+// Curvature scales of the condensed Hessian (closed forms at step 0 and zero attitude; S2 = sum_{k < h} k^2):
+//   torque space  g_tau[a] = 2 (Q_e[a] (dt^2 Iinv_aa)^2 S2 + Q_w[a] (dt Iinv_aa)^2 h)        (REF:165-184, 278-286)
+//   force space   g_F[a]   = 2 (Q_p[a] (dt^2 / m)^2 S2 + Q_v[a] (dt / m)^2 h)
+// force-like rows see g_F plus the torque curvature through the lever arm of the nominal CoM height, moment-like rows
+// g_tau; the soft end of the spectrum is 2 R.  The penalty fields of bmpc_params are the values AT THE REFERENCE PROBLEM
+// (REF:22-48 defaults, h = 10) and scale with these ratios, so that weights, step length, mass, inertia and horizon can
+// change without re-tuning (at h = 40 the stiff scale is 70 times the one at h = 10, and with
+// absolute ceilings the active rows of the early steps converge at 0.97 per iteration).
+struct CurvScales { double force, moment, soft; };
+CurvScales curvature_scales(const bmpc_params& p) {
+  double Iinv[9];
+  CurvScales c = {1.0, 1.0, 1.0};
+  if (!inv3(p.I, Iinv)) return c;
+  double s2 = 0;
+  for (int k = 1; k < p.h; ++k) s2 += (double)k * k;
+  const double dt = p.dt, h = p.h;
+  double gt[3], gf = 0, rmin = p.R[0];
+  for (int a = 0; a < 3; ++a) {
+    const double ii = std::fabs(Iinv[4 * a]);
+    gt[a] = 2 * (p.Q[a] * (dt * dt * ii) * (dt * dt * ii) * s2 + p.Q[6 + a] * (dt * ii) * (dt * ii) * h);
+    gf = std::fmax(gf, 2 * (p.Q[3 + a] * (dt * dt / p.m) * (dt * dt / p.m) * s2 + p.Q[9 + a] * (dt / p.m) * (dt / p.m) * h));
+  }
+  for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p.R[i]);
+  const double z0 = p.x_cmd[5];
+  c.force = gf + z0 * z0 * std::fmax(gt[0], gt[1]);
+  c.moment = std::fmax(gt[0], std::fmax(gt[1], gt[2]));
+  c.soft = rmin;
+  return c;
+}
+
 int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
-  if (!bmpc_supported_horizon(p.h)) return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", p.h);
+  if (!resolve_path(p.h, p.path)) return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d for path %d", p.h, p.path);
   if (p.half < 1) return fail(BMPC_ERR_INVALID, "half must be >= 1");
   if (!(p.dt > 0) || !(p.m > 0)) return fail(BMPC_ERR_INVALID, "dt and m must be positive");
   if (!(p.rho > 0) || !(p.rho_lo > 0) || !(p.rho_hi_f > 0) || !(p.rho_hi_m > 0) || !(p.rho_eq_scale > 0))
@@ -68,8 +110,21 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     d->tau_max[i] = p.tau_max[i]; d->tau_min[i] = p.tau_min[i];
     if (p.f_max[i] < p.f_min[i] || p.tau_max[i] < p.tau_min[i]) return fail(BMPC_ERR_INVALID, "upper bound below lower bound");
   }
-  d->rho = (float)p.rho; d->rho_eq = (float)(p.rho * p.rho_eq_scale); d->rho_lo = (float)p.rho_lo;
-  d->rho_hi_f = (float)p.rho_hi_f; d->rho_hi_m = (float)p.rho_hi_m;
+  double pf = 1, pm = 1, pr = 1;               // curvature of this problem relative to the reference problem
+  if (p.penalty_mode == BMPC_PENALTY_SCALED) {
+    bmpc_params ref;
+    bmpc_default_params(&ref, 10);
+    const CurvScales c0 = curvature_scales(ref), c1 = curvature_scales(p);
+    if (c0.force > 0 && c0.moment > 0 && c0.soft > 0 && c1.force > 0 && c1.moment > 0 && c1.soft > 0) {
+      pf = c1.force / c0.force; pm = c1.moment / c0.moment; pr = c1.soft / c0.soft;
+    }
+  } else if (p.penalty_mode != BMPC_PENALTY_ABSOLUTE) {
+    return fail(BMPC_ERR_INVALID, "unknown penalty_mode %d", p.penalty_mode);
+  }
+  d->rho = (float)(p.rho * std::sqrt(pr * pf));          // between the soft and the stiff end
+  d->rho_eq = (float)(p.rho * p.rho_eq_scale * pf);
+  d->rho_lo = (float)(p.rho_lo * pr);
+  d->rho_hi_f = (float)(p.rho_hi_f * pf); d->rho_hi_m = (float)(p.rho_hi_m * pm);
   d->eps_pri = (float)p.eps_pri; d->eps_dua = (float)p.eps_dua; d->kappa = (float)p.kappa;
   return BMPC_OK;
 }
@@ -96,6 +151,7 @@ struct bmpc_handle_s {
   int max_batch = 0;
   bmpc_params params;
   bmpc::DevParams dev;
+  int path = BMPC_PATH_DENSE;      // resolved kernel family (resolve_path)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -122,6 +178,12 @@ struct bmpc_handle_s {
 };
 
 namespace {
+
+// Horizons with a dense kernel (explicit 6h x 6h inverse held in registers).  h = 20 sits at 255 VGPRs; h = 22 / 24 were
+// built and dropped: a 5-wave workgroup caps a lane at 256 registers whatever the launch bounds say, the row halves no
+// longer fit (35 / 30 spilled registers) and 78 / 86 KB of LDS leave one workgroup per CU -- those horizons belong to the
+// stage-structured kernels (bmpc_stage.hip).
+#define BMPC_DENSE_HORIZONS(X) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
 
 template <int H>
 int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
@@ -152,14 +214,53 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
   return BMPC_OK;
 }
 
+template <int NP>
+int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                 const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+                 int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
+                 hipStream_t st) {
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : hd->order};
+  if (hd->warm_on && !dbg.assemble_only) {
+    const size_t need = (size_t)B * (5 * NP) * 12 * 6;       // [B][5 NP][12][6] doubles
+    if (need > hd->warm.n) hd->warm_valid = false;
+    HIP_TRY(hd->warm.ensure(need));
+    warm.buf = hd->warm.p;
+    warm.load = (hd->warm_valid && hd->warm_batch == B) ? 1 : 0;
+    warm.store = 1;
+    warm.shift = hd->warm_shift;
+    warm.theta = hd->warm_theta;
+    warm.adapt_start = hd->params.warm_adapt_start;
+  }
+  if (dbg.prof)
+    hipLaunchKernelGGL((bmpc::stage_kernel_prof<NP>), dim3(B), dim3(64), 0, st, hd->dev, B, x_fb, foot, contact,
+                       phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
+  else
+    hipLaunchKernelGGL((bmpc::stage_kernel<NP>), dim3(B), dim3(64), 0, st, hd->dev, B, x_fb, foot, contact,
+                       phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
+  HIP_TRY(hipGetLastError());
+  if (warm.buf) { hd->warm_valid = true; hd->warm_batch = B; }
+  return BMPC_OK;
+}
+
 int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
            const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
            int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
            hipStream_t st) {
+  // the stage-structured family (bmpc_stage.hip) is compiled per number of steps a lane owns, NP = ceil(h / 5)
+  const bool dense_views = dbg.assemble_only && (dbg.Gt || dbg.qt);      // Gt, qt only exist on the dense path
+  if (hd->path == BMPC_PATH_STAGE && !(dense_views && dense_horizon(hd->dev.h))) {
+    if (dense_views) return fail(BMPC_ERR_INVALID, "Gt / qt views exist for h <= 20 only (h=%d never forms them)", hd->dev.h);
+    switch ((hd->dev.h + 4) / 5) {
+#define BMPC_CASE(NN) case NN: return launch_stage<NN>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+      BMPC_CASE(2) BMPC_CASE(3) BMPC_CASE(4) BMPC_CASE(5) BMPC_CASE(6) BMPC_CASE(7) BMPC_CASE(8)
+#undef BMPC_CASE
+      default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
+    }
+  }
   switch (hd->dev.h) {
-    case 10: return launch_h<10>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
-    case 16: return launch_h<16>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
-    case 20: return launch_h<20>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+#define BMPC_CASE(HH) case HH: return launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+    BMPC_DENSE_HORIZONS(BMPC_CASE)
+#undef BMPC_CASE
     default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
   }
 }
@@ -187,7 +288,23 @@ int bmpc_abi_version(void) { return BMPC_ABI_VERSION; }
 
 const char* bmpc_last_error(void) { return g_err; }
 
-int bmpc_supported_horizon(int h) { return (h == 10 || h == 16 || h == 20) ? 1 : 0; }
+int bmpc_supported_horizon(int h) { return resolve_path(h, BMPC_PATH_AUTO) ? 1 : 0; }
+
+int bmpc_supported_horizon_path(int h, int path) { return resolve_path(h, path) ? 1 : 0; }
+
+int bmpc_effective_penalties(const bmpc_params* params, double* out5) {
+  if (!params || !out5) return fail(BMPC_ERR_INVALID, "null argument");
+  bmpc::DevParams d;
+  int rc = make_dev_params(*params, &d);
+  if (rc != BMPC_OK) return rc;
+  out5[0] = d.rho; out5[1] = d.rho_eq; out5[2] = d.rho_lo; out5[3] = d.rho_hi_f; out5[4] = d.rho_hi_m;
+  return BMPC_OK;
+}
+
+int bmpc_solver_path(bmpc_handle h) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  return h->path;
+}
 
 int bmpc_default_params(bmpc_params* p, int h) {
   if (!p) return fail(BMPC_ERR_INVALID, "null params");
@@ -240,6 +357,7 @@ int bmpc_create(bmpc_handle* out, const bmpc_params* params, int device, int max
   bmpc_handle h = new (std::nothrow) bmpc_handle_s();
   if (!h) return fail(BMPC_ERR_ALLOC, "out of host memory");
   h->device = device; h->max_batch = max_batch; h->params = *params; h->dev = dev;
+  h->path = resolve_path(params->h, params->path);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -262,7 +380,7 @@ int bmpc_destroy(bmpc_handle h) {
   h->ll_q.release(); h->ll_qd.release(); h->ll_pf.release(); h->ll_u0.release(); h->ll_tau.release();
   h->ll_t.release(); h->ll_c0.release();
   h->warm.release(); h->ro_controls.release(); h->ro_states.release(); h->ro_contact.release();
-  h->ro_phase.release(); h->ro_iters.release(); h->ro_status.release();
+  h->ro_phase.release(); h->ro_iters.release(); h->ro_status.release(); h->ro_order.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -276,7 +394,9 @@ int bmpc_set_params(bmpc_handle h, const bmpc_params* params) {
   bmpc::DevParams dev;
   int rc = make_dev_params(*params, &dev);
   if (rc != BMPC_OK) return rc;
+  if (resolve_path(params->h, params->path) != h->path) h->warm_valid = false;   // the two families keep different state
   h->params = *params; h->dev = dev;
+  h->path = resolve_path(params->h, params->path);
   return BMPC_OK;
 }
 
@@ -558,6 +678,7 @@ int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const floa
     if (rc != BMPC_OK) break;
     if (h->longest_first && !user_order && s > 0) {
       hipLaunchKernelGGL(bmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, st, B, h->ro_iters.p, h->ro_order.p);
+      if (hipGetLastError() != hipSuccess) { rc = fail(BMPC_ERR_HIP, "dispatch-order launch failed"); break; }
       h->order = h->ro_order.p;
     }
     rc = bmpc_solve_batch_device(h, B, x_fb, foot, h->ro_contact.p, h->ro_phase.p, x_cmd, mu, h->ro_controls.p,

@@ -1,0 +1,1190 @@
+// bmpc_stage.hip -- stage-structured solve kernels (gfx950 / CDNA4): the long-horizon path of the batched HECTOR MPC.
+//
+// SURVEY 8(f) row 4.  The dense kernels (bmpc_kernels.hip) invert K' = Gt + F (6h x 6h) explicitly: O(h^3) work, a row
+// half of the inverse per lane (255 VGPRs at h = 20) and an O(h^2) set-up table -- they end at h = 20.  This file keeps
+// the SPARSE stage structure the reference's equality block has (REF:203-216: X_i = A_i X_{i-1} + B_i U_i) instead:
+//
+//   * (Gt + F) gamma = beta is the optimality system of an LQ problem in the 12 SRBM states,
+//        min sum_i 1/2 a_i' Ft_i a_i - bt_i' a_i + 1/2 xi_i' 2Q xi_i,   xi_i = A_i xi_{i-1} + [0; a_i],   a = E gamma,
+//     A_i = [[I, C_i], [0, I]], C_i = dt blkdiag(Rinv_i, I) (REF:165-171, 183), E_i = dt blkdiag(Iw_i^-1, I/m) (REF:174-184).
+//     A backward Riccati recursion factorises it in h steps of 6x6 / 6x12 blocks (O(h) work and state), and a solve
+//     is one backward and one forward pass over the steps (oracle/riccati_model.py is the executable specification).
+//   * Gt itself is never formed: the tracking error err = s - x_ref + Gam_t W u is carried in the 12 h state
+//     coordinates (f64, one per lane and step), and the wrench-space gradient is its adjoint (two suffix sums over the
+//     steps).  Set-up is O(h) per lane.
+//   * The outer method is the one of the dense kernels, unchanged (ADMM in residual form, active-set adaptive
+//     penalties, f64 iterates and residual, f32 preconditioner: DESIGN.md sections 3, 4), so the iteration counts, the
+//     convergence record of the soaks and the parity numbers carry over; only the application of K^-1 differs.
+//
+// Thread map: ONE WAVE per instance.  Lane l = 12 q + 2 c + f: group q (5 groups; lanes 60..63 clone 56..59), component
+// c, foot f; the lane owns control variable c of foot f -- and state coordinate n = 2 c + f -- at the NP consecutive
+// steps j = q NP + s (s = 0 .. NP-1).  Steps past the horizon are PHANTOMS: they have their own LDS slots (the step
+// arrays hold 5 NP steps), read the inputs of step h - 1, do the same arithmetic as everybody else and are masked out
+// of everything that crosses steps (scans, the sequential passes, reductions, outputs) -- nothing is predicated on
+// them.  h is a launch parameter: the kernel is compiled per NP = ceil(h / 5) (NP = 2 .. 8: h = 8 .. 40).
+// No s_barrier anywhere: lanes of one wave exchange through LDS in program order (BMPC_WAVE_SYNC only fences the
+// compiler) and through DPP.  The two sequential passes of a solve run on the 12 lanes of a DPP row, one state
+// coordinate per lane, as 12x12 mat-vecs whose operands arrive by row broadcast (no LDS round trip in the chain).
+// An instance needs no register-resident matrix, so many instances share a CU: the path is bound by the latency of
+// its dependent chains, and throughput comes from the number of instances in flight.
+
+#ifndef BMPC_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace bmpc {
+
+#ifndef BMPC_EMU
+// value of lane N of the own DPP row (16 lanes): row_newbcast:N
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xf, 0xf, false));
+}
+#endif
+
+template <int NP>
+struct alignas(16) StageSmem {
+  static constexpr int HS = 5 * NP;            // step capacity
+  struct FootBlock { float d[HS][6][6][2]; };
+  // f64 6x6 scratch of the block algebra of ONE pass (5 steps), indexed by lane group
+  struct Fac {
+    double M0[5][6][6];        // D0 -> Ka^-1 D0 W_0^-1
+    double M1[5][6][6];        // D1 -> Ka^-1
+    double M2[5][6][6];        // B = T' D1 T -> L~_0
+    double Ka[5][6][6];
+  };
+  // exchange vectors of an iteration; never live together with the factor scratch
+  struct Itv {
+    RT wg[HS][2][6];           // y + rho (A x - z) on the general rows; x itself for the exact rebuild and the outputs
+    RT lam[HS][12];            // adjoint of the tracking error (acceleration space), and the scans' exchange
+    alignas(16) float r32[HS][2][6];   // KKT residual, control space
+    alignas(16) float bt[HS][6];       // right-hand side of the stage solve (E^-T beta)
+    float gs[HS][6];           // g = p2 - bt of the backward pass
+    float wv[HS][6];           // Sinv g
+    float av[HS][6];           // accelerations a = E gamma of the solve
+    alignas(16) float xi[HS][12];      // state response Gam_t gamma
+  };
+  union alignas(16) { Fac fac; Itv itv; } u;
+  RT tot[2][5][12];            // group totals of the scans over the steps (double buffered)
+  // block-diagonal part of K^-1, pairs {factor, G_f x factor} (see bmpc_kernels.hip); L~ = L E^-1 (acceleration space)
+  alignas(16) FootBlock LG[2];
+  alignas(16) FootBlock KG[2];
+  // stage solve: forward matrix Mf_i = [[0, C_i], [-K_i]] (12 x 12; rows 6..11 = minus the Riccati gain), S_i^-1, Ft_i
+  alignas(16) float Mf[HS][12][12];
+  alignas(16) float Sinv[HS][6][6];
+  alignas(16) float Ft[HS][6][6];
+  alignas(16) float Pm[12][12];   // Riccati recursion: cost-to-go
+  alignas(16) float Zm[12][12];   //                    Schur complement
+  alignas(16) float Tm[6][6];     //                    S^-1 Ft
+  float q2[12];                   // 2 Q
+  // step data
+  RT Iwi[HS][9];               // world inverse inertia
+  RT Iww[HS][9];               // world inertia
+  RT Rv[HS][9];                // R_inv (REF:160-164)
+  RT rr[HS][2][3];             // r_f = foot_ref - com_ref
+  RT s0[HS][12];               // free response
+  float muf[HS][2];
+  float rvg[HS][2][6];
+  RT Gu[6][6];
+  RT GuT[6][6];
+  float eyz[6];
+};
+
+// x with S x = b for a 6x6 SPD S given by its lower triangle (LDL', f32; every lane for itself)
+__device__ __forceinline__ void ldl6_solve(const float (&s)[6][6], const float (&b)[6], float (&x)[6]) {
+  float a[6][6], dinv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = 0; k <= i; ++k) a[i][k] = s[i][k];
+#pragma unroll
+  for (int jj = 0; jj < 6; ++jj) {
+    float d = a[jj][jj];
+#pragma unroll
+    for (int k = 0; k < jj; ++k) d = fmaf(-a[jj][k] * a[jj][k], a[k][k], d);
+    float r = rcp_approx(d);
+    r = fmaf(fmaf(-d, r, 1.f), r, r);
+    dinv[jj] = r;
+    a[jj][jj] = d;
+#pragma unroll
+    for (int i = jj + 1; i < 6; ++i) {
+      float v = a[i][jj];
+#pragma unroll
+      for (int k = 0; k < jj; ++k) v = fmaf(-a[i][k] * a[jj][k], a[k][k], v);
+      a[i][jj] = v * r;
+    }
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = fmaf(-a[i][k], y[k], v);
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float v = y[i] * dinv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v = fmaf(-a[k][i], x[k], v);
+    x[i] = v;
+  }
+}
+
+template <int NP, bool PROF>
+__device__ __forceinline__ void
+stage_body(const DevParams& P, const int B,
+           const float* __restrict__ x_fb, const float* __restrict__ foot,
+           const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase,
+           const float* __restrict__ x_cmd, const float* __restrict__ mu_in,
+           float* __restrict__ controls, float* __restrict__ states,
+           int32_t* __restrict__ iters_out, float* __restrict__ resid_out,
+           int32_t* __restrict__ status_out, int32_t* __restrict__ nfactor_out,
+           const DebugOut& dbg, const WarmArgs& warm) {
+  constexpr int HS = 5 * NP;
+  __shared__ StageSmem<NP> sm;
+
+  if ((int)blockIdx.x >= B) return;
+  const int inst = warm.order ? warm.order[blockIdx.x] : (int)blockIdx.x;
+  const int H = P.h;                           // NP = ceil(H / 5) (checked on the host)
+#ifdef BMPC_EMU
+  if (threadIdx.x == 0) std::memset(&sm, g_poison, sizeof(sm));
+  BMPC_WAVE_SYNC();
+#endif
+  long long t_start = 0, t_setup = 0, t_blocks = 0, t_ric = 0, t_mark = 0;
+  long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+#define BMPC_SSTAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
+  if constexpr (PROF) t_start = clock64();
+  const int l = threadIdx.x;
+  const int lc = l < 60 ? l : l - 4;           // lanes 60..63 clone lanes 56..59 (same indices, same data, same stores)
+  const bool lane_real = l < 60;
+  const int q = lc / 12;                       // lane group: steps q NP .. q NP + NP - 1
+  const int n = lc % 12;                       // state coordinate [e(3), p(3), w(3), v(3)] of the scans
+  const int c = n >> 1;                        // component of the control variable v = [f(3), m(3)]
+  const int f = n & 1;                         // foot
+  const int hf = f;
+  const int rn = (l & 15) < 12 ? (l & 15) : 11;   // state coordinate of the lane in the chains (DPP row; lanes 12..15 clone 11)
+  const RT dt = (RT)P.dt;
+  // steps of this lane (= LDS slots); past the horizon: phantoms with the inputs of the last step
+  int js[NP], jg[NP];
+  bool sreal[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    js[s] = q * NP + s;
+    sreal[s] = js[s] < H;
+    jg[s] = js[s] < H ? js[s] : H - 1;          // index into the per-step inputs in HBM
+  }
+
+  // scans over the steps of one value per (lane, step), f64: the lane's NP steps are consecutive, so a scan is a local
+  // pass in registers plus one exchange of the 5 group totals.  Steps past the horizon contribute nothing.
+  int n_scan = 0;
+  auto group_add = [&](RT run, bool suffix) -> RT {
+    RT (*tb)[12] = sm.tot[n_scan & 1];
+    ++n_scan;
+    tb[q][n] = run;
+    BMPC_WAVE_SYNC();
+    RT add = 0;
+#pragma unroll
+    for (int q2 = 0; q2 < 5; ++q2) {
+      const RT t = tb[q2][n];
+      add += (suffix ? q2 > q : q2 < q) ? t : (RT)0;
+    }
+    return add;
+  };
+  auto suffix_incl = [&](RT (&v)[NP]) {        // v[s] <- sum over steps j' >= j(s)
+    RT run = 0;
+#pragma unroll
+    for (int s = NP - 1; s >= 0; --s) { run += sreal[s] ? v[s] : (RT)0; v[s] = run; }
+    const RT add = group_add(run, true);
+#pragma unroll
+    for (int s = 0; s < NP; ++s) v[s] += add;
+  };
+  auto suffix_excl = [&](RT (&v)[NP]) {        // v[s] <- sum over steps j' > j(s)
+    RT run = 0;
+#pragma unroll
+    for (int s = NP - 1; s >= 0; --s) { const RT o = sreal[s] ? v[s] : (RT)0; v[s] = run; run += o; }
+    const RT add = group_add(run, true);
+#pragma unroll
+    for (int s = 0; s < NP; ++s) v[s] += add;
+  };
+  auto prefix_incl = [&](RT (&v)[NP]) {        // v[s] <- sum over steps j' <= j(s)
+    RT run = 0;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) { run += sreal[s] ? v[s] : (RT)0; v[s] = run; }
+    const RT add = group_add(run, false);
+#pragma unroll
+    for (int s = 0; s < NP; ++s) v[s] += add;
+  };
+
+  // ------------------------------------------------------------------ A. references, step data, free response
+  RT xfb[12], xc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    xfb[i] = (RT)x_fb[(size_t)inst * 12 + i];
+    xc[i] = x_cmd ? (RT)x_cmd[(size_t)inst * 12 + i] : (RT)P.x_cmd[i];
+  }
+  const int kph = phase[inst];
+  const RT xfb_n = (RT)x_fb[(size_t)inst * 12 + n];
+  const RT xc_n = x_cmd ? (RT)x_cmd[(size_t)inst * 12 + n] : (RT)P.x_cmd[n];
+  const RT xc_n6 = n < 6 ? (x_cmd ? (RT)x_cmd[(size_t)inst * 12 + n + 6] : (RT)P.x_cmd[n + 6]) : (RT)0;
+  const bool lead = lane_real && n == 0;       // one lane per (group, step)
+  RT e0[NP];                                   // free response - reference, coordinate n of the lane's steps
+  RT err[NP];                                  // tracking error s - x_ref + Gam_t W x (carried)
+  {
+    const int c0 = contact[(size_t)inst * H * 2 + 0], c1 = contact[(size_t)inst * H * 2 + 1];
+    const bool single = (c0 + c1) == 1;        // REF:102
+    const int kk = kph % P.half;               // REF:101
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = jg[s];
+      const int jst = js[s];
+      RT xr[12];                               // x_ref[:, j]  (REF:61-70)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        if (j == 0) xr[i] = xfb[i];
+        else if (i < 6) xr[i] = (xc[i + 6] != (RT)0) ? xfb[i] + xc[i + 6] * ((RT)j * dt) : xc[i];
+        else xr[i] = xc[i];
+      }
+      RT fr[6];                                // foot_ref[:, j]  (REF:72-109)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fr[i] = (RT)foot[(size_t)inst * 6 + i];
+      if (single && j >= P.half - kk) {
+        const bool second = j >= 2 * P.half - kk;
+        const RT hor = second ? (RT)0.5 * (RT)H * dt : (RT)0.5 * (RT)H / (RT)2 * dt;   // REF:74, 78
+        const RT fx = xfb[3] + xfb[9] * hor + (RT)P.kv * (xfb[3] - xc[3]);
+        const RT fy = (second ? xfb[10] : xfb[4]) + xfb[10] * hor + (RT)P.kv * (xfb[4] - xc[4]);  // REF:87 quirk
+        fr[0] = fx; fr[1] = fy; fr[2] = 0; fr[3] = fx; fr[4] = fy; fr[5] = 0;
+      }
+      if (lead && sreal[s]) {                  // debug views of the references (tests)
+        if (dbg.x_ref) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) dbg.x_ref[((size_t)inst * H + j) * 12 + i] = (double)xr[i];
+        }
+        if (dbg.foot_ref) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) dbg.foot_ref[((size_t)inst * H + j) * 6 + i] = (double)fr[i];
+        }
+      }
+      RT sy, cy, sp, cp, sr, cr;               // REF:151-153: yaw = x[0], pitch = x[1], roll = x[2]
+      sincos(xr[0], &sy, &cy);
+      sincos(xr[1], &sp, &cp);
+      sincos(xr[2], &sr, &cr);
+      // Rot = Rx(roll) Ry(pitch) Rz(yaw)   (scipy 'zyx' extrinsic, REF:154-156)
+      const RT Rot[9] = {cp * cy, -cp * sy, sp,
+                         cr * sy + sr * sp * cy, cr * cy - sr * sp * sy, -sr * cp,
+                         sr * sy - cr * sp * cy, sr * cy + cr * sp * sy, cr * cp};
+      RT T[9], Iwi[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          T[3 * a + b] = (RT)P.Iinv[3 * a] * Rot[b] + (RT)P.Iinv[3 * a + 1] * Rot[3 + b] + (RT)P.Iinv[3 * a + 2] * Rot[6 + b];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          Iwi[3 * a + b] = Rot[a] * T[b] + Rot[3 + a] * T[3 + b] + Rot[6 + a] * T[6 + b];   // Rot' Iinv Rot = (Rot' I Rot)^-1
+      const RT tp = sp / cp;
+      const RT Rv[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};             // REF:160-164 inverted
+      if (lead) {
+        // world inertia Iw = Rot' I Rot as the inverse of Iwi (3x3 cofactors)
+        const RT c00 = Iwi[4] * Iwi[8] - Iwi[5] * Iwi[7], c01 = Iwi[5] * Iwi[6] - Iwi[3] * Iwi[8], c02 = Iwi[3] * Iwi[7] - Iwi[4] * Iwi[6];
+        const RT idet = (RT)1 / (Iwi[0] * c00 + Iwi[1] * c01 + Iwi[2] * c02);
+        const RT Iww[9] = {c00 * idet, (Iwi[2] * Iwi[7] - Iwi[1] * Iwi[8]) * idet, (Iwi[1] * Iwi[5] - Iwi[2] * Iwi[4]) * idet,
+                           c01 * idet, (Iwi[0] * Iwi[8] - Iwi[2] * Iwi[6]) * idet, (Iwi[2] * Iwi[3] - Iwi[0] * Iwi[5]) * idet,
+                           c02 * idet, (Iwi[1] * Iwi[6] - Iwi[0] * Iwi[7]) * idet, (Iwi[0] * Iwi[4] - Iwi[1] * Iwi[3]) * idet};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { sm.Iwi[jst][k] = Iwi[k]; sm.Iww[jst][k] = Iww[k]; sm.Rv[jst][k] = Rv[k]; }
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) sm.rr[jst][ft][a] = fr[3 * ft + a] - xr[3 + a];       // REF:174-175
+      }
+      // coordinate n of x_ref[:, j], and the term of the free response that is a sum over the steps:
+      // euler_j = euler_fb + dt sum_{i <= j} Rinv_i omega_fb  (the other coordinates are closed forms)
+      const RT xrn = (j == 0) ? xfb_n : ((n < 6 && xc_n6 != (RT)0) ? xfb_n + xc_n6 * ((RT)j * dt) : xc_n);
+      RT rw = 0;
+      if (n < 3) rw = dt * ((n == 0 ? Rv[0] : (n == 1 ? Rv[3] : Rv[6])) * xfb[6] + (n == 0 ? Rv[1] : (n == 1 ? Rv[4] : Rv[7])) * xfb[7] +
+                            (n == 0 ? Rv[2] : (n == 1 ? Rv[5] : Rv[8])) * xfb[8]);
+      err[s] = rw;
+      e0[s] = xrn;
+    }
+  }
+  BMPC_WAVE_SYNC();
+  prefix_incl(err);
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    const int j = js[s];
+    const RT j1 = (RT)(jg[s] + 1);
+    RT e = xfb_n + err[s];                     // (err is zero for n >= 3)
+    if (n >= 3 && n < 6) e += dt * j1 * (n == 3 ? xfb[9] : (n == 4 ? xfb[10] : xfb[11]));
+    if (n == 5) e -= (RT)P.g * dt * dt * (RT)jg[s] * j1 / 2;
+    if (n == 11) e -= (RT)P.g * dt * j1;
+    sm.s0[j][n] = e;
+    e0[s] = e - e0[s];
+    err[s] = e0[s];                            // x = 0
+  }
+  if (dbg.assemble_only) return;
+  // rows 0..5 of the forward matrices, [0, C_i] (constant over the factorisations), and 2 Q
+  for (int e = l; e < H * 72; e += 64) {
+    const int i = e / 72, a = (e % 72) / 12, b = e % 12;
+    float v = 0.f;
+    if (b >= 6) {
+      const int k = b - 6;
+      v = (a < 3 && k < 3) ? (float)(dt * sm.Rv[i][3 * (a < 3 ? a : 0) + (k < 3 ? k : 0)]) : (a == k ? (float)dt : 0.f);
+    }
+    sm.Mf[i][a][b] = v;
+  }
+  if (l < 12) sm.q2[l] = 2.f * (float)P.Q[l];
+  if constexpr (PROF) t_setup = clock64() - t_start;
+
+  // ------------------------------------------------------------------ C. constraint data (own variable, per step)
+  float lb[NP], ub[NP], cmu[NP];
+  bool eqb[NP];
+  const float R2v = (float)(c < 3 ? P.R2[3 * f + c] : P.R2[6 + 3 * f + (c - 3)]);
+  {
+    float ey[3], ez[3];                        // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
+    {
+      RT sr, cr, sp, cp, sy, cy;
+      sincos(xfb[0], &sr, &cr);
+      sincos(xfb[1], &sp, &cp);
+      sincos(xfb[2], &sy, &cy);
+      ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
+      ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { sm.eyz[a] = ey[a]; sm.eyz[3 + a] = ez[a]; }
+      float G[6][6];
+      general_rows(0.f, ey, ez, (float)P.lh, (float)P.lt, G);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int b2 = 0; b2 < 6; ++b2) { sm.Gu[r][b2] = (RT)G[r][b2]; sm.GuT[b2][r] = (RT)G[r][b2]; }
+    }
+    const int a = c < 3 ? c : c - 3;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      const float cont = (float)contact[((size_t)inst * H + jg[s]) * 2 + f];
+      const float muf = mu_in ? mu_in[((size_t)inst * H + jg[s]) * 2 + f] : (float)P.mu;
+      if (c == 0) sm.muf[j][f] = muf;
+      ub[s] = cont * (float)(c < 3 ? P.f_max[a] : P.tau_max[a]);      // REF:240-249
+      lb[s] = cont * (float)(c < 3 ? P.f_min[a] : P.tau_min[a]);
+      eqb[s] = lb[s] == ub[s];
+      cmu[s] = c == 2 ? -muf : 0.f;
+    }
+  }
+
+  // ------------------------------------------------------------------ D. factor: block-diagonal factors and the Riccati recursion
+  float rvb[NP], rvg[NP];                     // penalties of this lane's box row / general row
+  RT irvb[NP], irvg[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    rvb[s] = eqb[s] ? P.rho_eq : P.rho; rvg[s] = P.rho;
+    irvb[s] = (RT)1 / (RT)rvb[s]; irvg[s] = (RT)1 / (RT)rvg[s];
+  }
+
+  auto factor = [&]() {
+    if constexpr (PROF) t_mark = clock64();
+#pragma unroll
+    for (int s = 0; s < NP; ++s) sm.rvg[js[s]][f][c] = rvg[s];
+    BMPC_WAVE_SYNC();
+    int co = c;
+    BMPC_OPAQUE(co);
+    double mkd[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mkd[k] = (co == k) ? 1.0 : 0.0;
+    const float lh = (float)P.lh, lt = (float)P.lt;
+    float ey[3], ez[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ey[a] = sm.eyz[a]; ez[a] = sm.eyz[3 + a]; }
+    const double idt = 1.0 / (double)P.dt, mdt = (double)P.m / (double)P.dt;
+    // ---- 6x6 block algebra in f64, one pass (5 steps) at a time through the scratch; bmpc_kernels.hip has the
+    // derivation.  Here the wrench space is the ACCELERATION space a = E gamma: L~ = L E^-1, Ft = E^-T F E^-1.
+#pragma unroll 1
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      const float muf = sm.muf[j][f];
+      float rf[2][3];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rf[ft][a] = (float)sm.rr[j][ft][a];
+      double Ei[9];                              // E^-1 torque block: Iw / dt
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Ei[k] = sm.Iww[j][k] * idt;
+      double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
+      {
+        const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) Tm[p][r] = (p == r) ? 1.0 : 0.0;
+        Tm[3][1] = -dr[2]; Tm[3][2] = dr[1];
+        Tm[4][0] = dr[2];  Tm[4][2] = -dr[0];
+        Tm[5][0] = -dr[1]; Tm[5][1] = dr[0];
+      }
+      double Tcol[6], Trow[6];                   // T[:, c] and T[c, :]
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) { a1 = fma(mkd[cc], Tm[p][cc], a1); a2 = fma(mkd[cc], Tm[cc][p], a2); }
+        Tcol[p] = a1; Trow[p] = a2;
+      }
+      // D_f = 2R + A' diag(rv) A: row c of the own foot's block
+      double m3[6];
+      {
+        float G[6][6];
+        general_rows(muf, ey, ez, lh, lt, G);
+        double wc[6];                            // rho_r * G[r][c]
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double gc = (double)sm.GuT[co][r] - ((co == 2 && r < 4) ? (double)muf : 0.0);
+          wc[r] = (double)sm.rvg[j][f][r] * gc;
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) sacc = fma(wc[r], (double)G[r][b], sacc);
+          m3[b] = fma(mkd[b], (double)R2v + (double)rvb[s], sacc);
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[q][c][b] = m3[b];
+      }
+      BMPC_WAVE_SYNC();
+      const bool on0 = hf == 0, on1 = hf == 1;
+      double urow[6];                             // row c of U~ = E^-T W_0^-T D0
+      double ka[6];                               // row c of Ka^-1
+      if (on0) {
+        double yq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        row_times_mat6(Tcol, sm.u.fac.M1[q], yq);
+        double brow[6];                           // row c of B
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) sacc = fma(yq[r], Tm[r][b], sacc);
+          brow[b] = sacc;
+          sm.u.fac.Ka[q][c][b] = m3[b] + sacc;
+        }
+        // U~ = E^-T W_0^-T D0,  W_0^-T = [[0, I], [I, [r_0]x]]: row c of E^-T W_0^-T is a combination of rows of W_0^-T
+        double wti[6];
+        {
+          const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
+          double Wt[6][6];
+#pragma unroll
+          for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) Wt[p][r] = 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { Wt[a][3 + a] = 1.0; Wt[3 + a][a] = 1.0; }
+          Wt[3][4] = -r0[2]; Wt[3][5] = r0[1];
+          Wt[4][3] = r0[2];  Wt[4][5] = -r0[0];
+          Wt[5][3] = -r0[1]; Wt[5][4] = r0[0];
+          // E^-T = blkdiag(Iw / dt, (m / dt) I) (Iw symmetric): row c < 3 mixes rows 0..2 of W_0^-T
+          double ecol[6];                         // column c of E^-1 = row c of E^-T
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            double v = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) v = fma(mkd[cc], p < 3 ? Ei[3 * p + cc] : 0.0, v);
+#pragma unroll
+            for (int cc = 3; cc < 6; ++cc) v = fma(mkd[cc], p == cc ? mdt : 0.0, v);
+            ecol[p] = v;
+          }
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            double a1 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) a1 = fma(ecol[p], Wt[p][r], a1);
+            wti[r] = a1;
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) urow[b] = 0.0;
+        row_times_mat6(wti, sm.u.fac.M0[q], urow);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) sm.u.fac.M2[q][c][b] = brow[b];
+      }
+      BMPC_WAVE_SYNC();                         // Ka, B published; D1 consumed
+      inv6_row(sm.u.fac.Ka[q], co, ka);           // both lanes of the row, each for itself: no exchange
+      if (on0) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) sm.u.fac.M1[q][c][b] = ka[b];     // the whole Ka^-1 is needed for T Ka^-1 below
+      }
+      double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
+      if (on0) row_times_mat6(ka, sm.u.fac.M2[q], xk);
+      if (on1) row_times_mat6(ka, sm.u.fac.M0[q], xk);
+      BMPC_WAVE_SYNC();                         // B, D0 consumed; Ka^-1 published
+      {
+        const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
+        // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0];  then (.) E^-1
+        double w0[6], cr[3], wE[6];
+        const double q1[3] = {xk[3], xk[4], xk[5]};
+        cross3(q1, r0, cr);
+        w0[0] = xk[3]; w0[1] = xk[4]; w0[2] = xk[5];
+        w0[3] = xk[0] - cr[0]; w0[4] = xk[1] - cr[1]; w0[5] = xk[2] - cr[2];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          wE[b] = w0[0] * Ei[b] + w0[1] * Ei[3 + b] + w0[2] * Ei[6 + b];
+          wE[3 + b] = w0[3 + b] * mdt;
+        }
+        if (hf == 0) {
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            sm.LG[0].d[j][c][b][0] = (float)wE[b];
+            sm.u.fac.M2[q][c][b] = wE[b];         // L~_0 rows for Ft
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 6; ++b) sm.u.fac.M0[q][c][b] = wE[b];   // Ka^-1 D0 W_0^-1 E^-1 rows for L~_1
+        }
+      }
+      BMPC_WAVE_SYNC();
+      if (on0) {
+        double fv64[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        row_times_mat6(urow, sm.u.fac.M2[q], fv64);     // Ft = U~ L~_0
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          sm.KG[0].d[j][c][b][0] = (float)ka[b];
+          sm.Ft[j][c][b] = (float)fv64[b];
+        }
+      }
+      if (on1) {
+        double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        row_times_mat6(Trow, sm.u.fac.M0[q], sl);       // L~_1 = T (Ka^-1 D0 W_0^-1 E^-1)
+        row_times_mat6(Trow, sm.u.fac.M1[q], sk);       // T Ka^-1
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          sm.LG[1].d[j][c][b][0] = (float)sl[b];
+          sm.KG[1].d[j][c][b][0] = (float)sk[b];
+        }
+      }
+      BMPC_WAVE_SYNC();
+      {                                          // rows c of G_f Kn_f and G_f L~_f (f32, from the stored f32 factors)
+        float gr[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[co][b] - ((b == 2 && co < 4) ? muf : 0.f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          float gk = 0.f, gl = 0.f;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            gk = fmaf(gr[b], sm.KG[f].d[j][b][i][0], gk);
+            gl = fmaf(gr[b], sm.LG[f].d[j][b][i][0], gl);
+          }
+          sm.KG[f].d[j][c][i][1] = gk;
+          sm.LG[f].d[j][c][i][1] = gl;
+        }
+      }
+      BMPC_WAVE_SYNC();                         // the scratch is reused by the next pass
+    }
+    if constexpr (PROF) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
+
+    // ---- backward Riccati recursion over the steps (f32; oracle/riccati_model.py::factor).  Every lane works:
+    //   R2  column jn of [M | Ft | I] solved against S = Ft + Pi22 (each lane its own LDL'): gain K, T = S^-1 Ft, S^-1
+    //   R3  Schur complement Z = Pi - Pi[:,2] S^-1 Pi[2,:], cancellation-free in the (., 2) blocks
+    //   R4  P11 = Z11, P12 = Z11 C + Z12          R5  P22 = C' P12 + Z12' C + Z22
+    {
+      for (int e = l; e < 144; e += 64) sm.Pm[e / 12][e % 12] = 0.f;
+      BMPC_WAVE_SYNC();
+      const float dtf = (float)P.dt;
+      const int jn = l < 24 ? l : 23;           // column of [M | Ft | I] this lane solves (lanes 24.. repeat column 23)
+      // C_i[a][k] (a, k < 3: dt Rinv_i; the translational block is dt I) is read from rows 0..5 of Mf_i
+#define BMPC_CI(a, k) sm.Mf[i][a][6 + (k)]
+#pragma unroll 1
+      for (int i = H - 1; i >= 0; --i) {
+        // R2
+        {
+          float S[6][6], rhs[6], x[6];
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) S[a][b] = sm.Ft[i][a][b] + sm.Pm[6 + a][6 + b] + (a == b ? sm.q2[6 + a] : 0.f);
+          if (jn < 6) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) rhs[m] = sm.Pm[6 + m][jn];
+          } else if (jn < 12) {
+            const int k = jn - 6;
+            const float qk = sm.q2[6 + k];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+              float v = sm.Pm[6 + m][6 + k] + (m == k ? qk : 0.f);
+              if (k < 3) v += sm.Pm[6 + m][0] * BMPC_CI(0, k) + sm.Pm[6 + m][1] * BMPC_CI(1, k) + sm.Pm[6 + m][2] * BMPC_CI(2, k);
+              else v += dtf * sm.Pm[6 + m][k];
+              rhs[m] = v;
+            }
+          } else if (jn < 18) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) rhs[m] = sm.Ft[i][m][jn - 12];
+          } else {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) rhs[m] = (m == jn - 18) ? 1.f : 0.f;
+          }
+          ldl6_solve(S, rhs, x);
+          if (jn < 12) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) sm.Mf[i][6 + m][jn] = -x[m];
+          } else if (jn < 18) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) sm.Tm[m][jn - 12] = x[m];
+          } else {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) sm.Sinv[i][m][jn - 18] = x[m];
+          }
+        }
+        BMPC_WAVE_SYNC();
+        // R3: entries 0..35 Z11, 36..71 Z12, 72..107 Z22 (Z11, Z22 symmetrised)
+        {
+          auto zentry = [&](int e) {
+            const int blk = e / 36, a = (e % 36) / 6, b = e % 6;
+            if (blk == 0) {
+              // Z11[a][b] = Pi11[a][b] + sum_m Pi12[a][m] Mf[6 + m][b]   (rows 6.. of Mf are -K)
+              const float qd = a == b ? sm.q2[a] : 0.f;
+              float v1 = sm.Pm[a][b] + qd, v2 = sm.Pm[b][a] + qd;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) {
+                v1 = fmaf(sm.Pm[a][6 + m], sm.Mf[i][6 + m][b], v1);
+                v2 = fmaf(sm.Pm[b][6 + m], sm.Mf[i][6 + m][a], v2);
+              }
+              sm.Zm[a][b] = 0.5f * (v1 + v2);
+            } else if (blk == 1) {
+              float v = 0.f;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) v = fmaf(sm.Pm[a][6 + m], sm.Tm[m][b], v);
+              sm.Zm[a][6 + b] = v;
+              sm.Zm[6 + b][a] = v;
+            } else {
+              const float qa = sm.q2[6 + a], qb = sm.q2[6 + b];
+              float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) {
+                v1 = fmaf(sm.Pm[6 + a][6 + m] + (a == m ? qa : 0.f), sm.Tm[m][b], v1);
+                v2 = fmaf(sm.Pm[6 + b][6 + m] + (b == m ? qb : 0.f), sm.Tm[m][a], v2);
+              }
+              sm.Zm[6 + a][6 + b] = 0.5f * (v1 + v2);
+            }
+          };
+          zentry(l);
+          if (l + 64 < 108) zentry(l + 64);
+        }
+        BMPC_WAVE_SYNC();
+        // R4: P11 = Z11 (lanes 0..35), P12 = Z11 C + Z12 (lanes 28..63)
+        {
+          if (l < 36) {
+            const int a = l / 6, b = l % 6;
+            sm.Pm[a][b] = sm.Zm[a][b];
+          }
+          if (l >= 28) {
+            const int e2 = l - 28, a2 = e2 / 6, k = e2 % 6;
+            float v = sm.Zm[a2][6 + k];
+            if (k < 3) v += sm.Zm[a2][0] * BMPC_CI(0, k) + sm.Zm[a2][1] * BMPC_CI(1, k) + sm.Zm[a2][2] * BMPC_CI(2, k);
+            else v += dtf * sm.Zm[a2][k];
+            sm.Pm[a2][6 + k] = v;
+            sm.Pm[6 + k][a2] = v;
+          }
+        }
+        BMPC_WAVE_SYNC();
+        // R5: P22[k][k2] = (C' P12)[k][k2] + (Z12' C)[k][k2] + Z22[k][k2]
+        if (l < 36) {
+          const int k = l / 6, k2 = l % 6;
+          float v = sm.Zm[6 + k][6 + k2];
+          if (k < 3) v += BMPC_CI(0, k) * sm.Pm[0][6 + k2] + BMPC_CI(1, k) * sm.Pm[1][6 + k2] + BMPC_CI(2, k) * sm.Pm[2][6 + k2];
+          else v += dtf * sm.Pm[k][6 + k2];
+          if (k2 < 3) v += sm.Zm[0][6 + k] * BMPC_CI(0, k2) + sm.Zm[1][6 + k] * BMPC_CI(1, k2) + sm.Zm[2][6 + k] * BMPC_CI(2, k2);
+          else v += dtf * sm.Zm[k2][6 + k];
+          sm.Pm[6 + k][6 + k2] = v;
+        }
+        BMPC_WAVE_SYNC();
+      }
+#undef BMPC_CI
+    }
+    if constexpr (PROF) t_ric += clock64() - t_mark;
+  };
+
+  int nfac = 0;
+  bool need_factor = true;
+
+  // ------------------------------------------------------------------ E. ADMM iterations
+  RT xo[NP], zb[NP], zg[NP], yb[NP], yg[NP], axg[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) { xo[s] = 0; zb[s] = 0; zg[s] = 0; yb[s] = 0; yg[s] = 0; axg[s] = 0; }
+  const RT alpha = (RT)P.alpha;
+  int it = 0, status = 1;
+  const int check_every = P.check_every > 0 ? P.check_every : 1;
+  int next_check = 2 * check_every;
+  constexpr int REFRESH_ITERS = 20;
+  int next_refresh = REFRESH_ITERS;
+  constexpr float FAR = 1.0e3f;
+  int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
+  while (next_adapt < 1) next_adapt += P.adapt_every;
+  float res_p = 0.f, res_s = 0.f;
+  const RT idt_r = (RT)1 / dt, dtm = dt / (RT)P.m;
+
+  // exact axg and err from x (f64): err = e0 + Gam_t W x by two prefix sums over the steps
+  auto refresh = [&]() {
+#pragma unroll
+    for (int s = 0; s < NP; ++s) sm.u.itv.wg[js[s]][f][c] = xo[s];
+    BMPC_WAVE_SYNC();
+    RT v2[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      RT xblk[2][6], gu[6];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) xblk[ft][b] = sm.u.itv.wg[j][ft][b];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) gu[b] = sm.Gu[c][b];
+      {
+        RT a = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) a += gu[b] * (f == 0 ? xblk[0][b] : xblk[1][b]);
+        const RT negmu = c < 4 ? -(RT)sm.muf[j][f] : (RT)0;
+        axg[s] = a + negmu * (f == 0 ? xblk[0][2] : xblk[1][2]);
+      }
+      // acceleration of state coordinate n >= 6 at step j: (E W x)[n - 6]
+      RT acc = 0;
+      if (n >= 9) {
+        const int k = n - 9;
+        acc = dtm * ((k == 0 ? xblk[0][0] : (k == 1 ? xblk[0][1] : xblk[0][2])) + (k == 0 ? xblk[1][0] : (k == 1 ? xblk[1][1] : xblk[1][2])));
+      } else if (n >= 6) {
+        RT t0[3], t1[3], tau[3];
+        const RT r0[3] = {sm.rr[j][0][0], sm.rr[j][0][1], sm.rr[j][0][2]};
+        const RT r1[3] = {sm.rr[j][1][0], sm.rr[j][1][1], sm.rr[j][1][2]};
+        cross3(r0, &xblk[0][0], t0);
+        cross3(r1, &xblk[1][0], t1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tau[k] = t0[k] + t1[k] + xblk[0][3 + k] + xblk[1][3 + k];
+        const int k = n - 6;
+        acc = dt * (sm.Iwi[j][3 * k] * tau[0] + sm.Iwi[j][3 * k + 1] * tau[1] + sm.Iwi[j][3 * k + 2] * tau[2]);
+      }
+      v2[s] = acc;
+    }
+    prefix_incl(v2);                            // (w, v) part of the state response (zero for n < 6)
+    // (e, p) part: sum_{i <= j} C_i xi2_{i-1}: the lanes n < 6 need xi2 of the step before, other coordinates
+#pragma unroll
+    for (int s = 0; s < NP; ++s) sm.u.itv.lam[js[s]][n] = v2[s];
+    BMPC_WAVE_SYNC();
+    RT v1[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      RT d = 0;
+      if (n < 6 && j > 0) {
+        if (n < 3) d = dt * (sm.Rv[j][3 * n] * sm.u.itv.lam[j - 1][6] + sm.Rv[j][3 * n + 1] * sm.u.itv.lam[j - 1][7] + sm.Rv[j][3 * n + 2] * sm.u.itv.lam[j - 1][8]);
+        else d = dt * sm.u.itv.lam[j - 1][6 + n];
+      }
+      v1[s] = d;
+    }
+    prefix_incl(v1);
+#pragma unroll
+    for (int s = 0; s < NP; ++s) err[s] = e0[s] + (n < 6 ? v1[s] : v2[s]);
+  };
+
+  if (warm.buf && warm.load) {                 // wave-uniform
+    // Start from the previous solve of this batch slot (layout [B][HS][12][6]); see bmpc_kernels.hip.
+    bool ok = true;
+    double wv[NP][6];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      int jw = js[s] + warm.shift;
+      jw = jw > H - 1 ? H - 1 : jw;
+      const double* src = warm.buf + (((size_t)inst * HS + jw) * 12 + n) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) wv[s][k] = src[k];
+      const float pb0 = __int_as_float(__double2loint(wv[s][5])), pg0 = __int_as_float(__double2hiint(wv[s][5]));
+      ok = ok && pb0 > 0.f && pg0 > 0.f && pb0 < 3.0e38f && pg0 < 3.0e38f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ok = ok && (fabs(wv[s][k]) < 1.0e300);
+    }
+    ok = wave_umax(ok ? 0u : 1u) == 0u;        // all of the instance's state or none of it
+    if (ok) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const float pb0 = __int_as_float(__double2loint(wv[s][5])), pg0 = __int_as_float(__double2hiint(wv[s][5]));
+        xo[s] = wv[s][0];
+        zb[s] = fmin(fmax(wv[s][1], (RT)lb[s]), (RT)ub[s]);
+        zg[s] = fmin(wv[s][2], (RT)0);
+        yb[s] = wv[s][3];
+        yg[s] = wv[s][4];
+        const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+        rvb[s] = eqb[s] ? P.rho_eq : fminf(fmaxf(P.rho * powf(pb0 / P.rho, warm.theta), P.rho_lo), hib);
+        rvg[s] = fminf(fmaxf(P.rho * powf(pg0 / P.rho, warm.theta), P.rho_lo), hig);
+        irvb[s] = (RT)1 / (RT)rvb[s]; irvg[s] = (RT)1 / (RT)rvg[s];
+      }
+    }
+    refresh();
+    if (ok && warm.adapt_start > 0 && P.adapt_every > 0) next_adapt = warm.adapt_start;
+    if (ok) next_check = check_every;
+  }
+
+#pragma unroll 1
+  for (it = 0; it < P.max_iter;) {
+    if (need_factor) {                         // wave-uniform
+      factor();
+      ++nfac;
+      need_factor = false;
+    }
+    if constexpr (PROF) t_last = clock64();
+    // --- P0: adjoint of the tracking error: lam = sum_{i >= j} (A_{i+1} .. A_{j+1})' 2Q err_i (acceleration space);
+    //     the wrench-space gradient is gb = E' lam2.  Two suffix sums over the steps.
+    {
+      RT v[NP];
+#pragma unroll
+      for (int s = 0; s < NP; ++s) v[s] = (RT)2 * (RT)P.Q[n] * err[s];
+      suffix_incl(v);                           // n < 6: lam1;  n >= 6: the own part of lam2
+#pragma unroll
+      for (int s = 0; s < NP; ++s) sm.u.itv.lam[js[s]][n] = v[s];
+      BMPC_WAVE_SYNC();
+      RT cpl[NP];                               // C_{i}' lam1_{i} of the steps i > j enters lam2_j
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const int j = js[s];
+        RT d = 0;
+        if (n >= 9) d = dt * sm.u.itv.lam[j][n - 6];
+        else if (n >= 6) {
+          const int k = n - 6;
+          d = dt * (sm.Rv[j][k] * sm.u.itv.lam[j][0] + sm.Rv[j][3 + k] * sm.u.itv.lam[j][1] + sm.Rv[j][6 + k] * sm.u.itv.lam[j][2]);
+        }
+        cpl[s] = d;
+      }
+      suffix_excl(cpl);
+#pragma unroll
+      for (int s = 0; s < NP; ++s)
+        if (n >= 6) sm.u.itv.lam[js[s]][n] = v[s] + cpl[s];
+    }
+    // --- P1: row residuals w = y + rho (A x - z)
+    RT wb[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      wb[s] = yb[s] + widen(rvb[s]) * (xo[s] - zb[s]);
+      sm.u.itv.wg[js[s]][f][c] = yg[s] + widen(rvg[s]) * (axg[s] - zg[s]);
+    }
+    BMPC_WAVE_SYNC();
+    BMPC_SSTAMP(0)
+    // --- P2: KKT residual in control space r = W' gb + 2R x + A' w
+    {
+      RT gut[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) gut[r] = sm.GuT[c][r];
+      const int a3 = c < 3 ? c : c - 3;
+      const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const int j = js[s];
+        RT l2[6], wq[6], iw[9];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { l2[k] = sm.u.itv.lam[j][6 + k]; wq[k] = sm.u.itv.wg[j][f][k]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) iw[k] = sm.Iwi[j][k];
+        const RT rx0 = c < 3 ? sm.rr[j][f][i2] : (RT)0, rx1 = c < 3 ? sm.rr[j][f][i1] : (RT)0;
+        BMPC_SCHED_BARRIER();
+        RT gt[3];                                // torque part of gb = E' lam2
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gt[k] = dt * (iw[k] * l2[0] + iw[3 + k] * l2[1] + iw[6 + k] * l2[2]);
+        const RT g1 = i1 == 0 ? gt[0] : (i1 == 1 ? gt[1] : gt[2]), g2 = i2 == 0 ? gt[0] : (i2 == 1 ? gt[1] : gt[2]);
+        const RT gta = a3 == 0 ? gt[0] : (a3 == 1 ? gt[1] : gt[2]);
+        const RT gfa = dtm * (a3 == 0 ? l2[3] : (a3 == 1 ? l2[4] : l2[5]));
+        const RT gsel = c < 3 ? gfa : gta;
+        RT r = widen(R2v) * xo[s] + wb[s];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r += gut[k] * wq[k];
+        r += widen(cmu[s]) * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
+        const RT wt = g1 * rx0 - g2 * rx1 + gsel;
+        sm.u.itv.r32[j][f][c] = (float)(r + wt);
+      }
+    }
+    BMPC_WAVE_SYNC();
+    BMPC_SSTAMP(1)
+    // --- P3: right-hand side of the stage solve bt = L~' r (own foot's part, summed over the pair), and the
+    //     null-space part of the step: t = N' r = r_0 - T' r_1;  foot 0 gets Ka^-1 t, foot 1 -(T Ka^-1) t
+    f2 ddk[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      float rj[2][6], lcol[6];
+      f2 kg[6];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int i = 0; i < 6; i += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(&sm.u.itv.r32[j][ft][i]);
+          rj[ft][i] = v.x; rj[ft][i + 1] = v.y;
+        }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        lcol[i] = sm.LG[f].d[j][i][c][0];
+        kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
+      }
+      const float d0 = (float)sm.rr[j][0][0] - (float)sm.rr[j][1][0], d1 = (float)sm.rr[j][0][1] - (float)sm.rr[j][1][1],
+                  d2 = (float)sm.rr[j][0][2] - (float)sm.rr[j][1][2];
+      BMPC_SCHED_BARRIER();
+      float bsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bsum = fmaf(lcol[i], f == 0 ? rj[0][i] : rj[1][i], bsum);
+      bsum += pair_swap(bsum);
+      sm.u.itv.bt[j][c] = bsum;                 // both lanes of the pair: same value
+      float tn[6];
+      tn[0] = rj[0][0] - rj[1][0] + (d1 * rj[1][5] - d2 * rj[1][4]);
+      tn[1] = rj[0][1] - rj[1][1] + (d2 * rj[1][3] - d0 * rj[1][5]);
+      tn[2] = rj[0][2] - rj[1][2] + (d0 * rj[1][4] - d1 * rj[1][3]);
+      tn[3] = rj[0][3] - rj[1][3];
+      tn[4] = rj[0][4] - rj[1][4];
+      tn[5] = rj[0][5] - rj[1][5];
+      f2 dd = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(kg[i], f2{tn[i], tn[i]}, dd);
+      ddk[s] = f == 1 ? -dd : dd;
+    }
+    BMPC_WAVE_SYNC();
+    BMPC_SSTAMP(2)
+    // --- P4: stage solve.  Backward pass: u = [p1; g], g = p2 - bt_i;  p <- p + Mf_i' u   (p_i = A_i' p_{i+1} - K_i' g_i);
+    //     then w = Sinv g in parallel; forward pass: xi <- xi + Mf_i xi - [0; w_i]  (a_i = -K_i xi_{i-1} - w_i).
+    //     One state coordinate per lane of a DPP row, operands by row broadcast: no LDS round trip in the chain.
+    {
+      const int r6 = rn >= 6 ? rn - 6 : 0;
+      float p = 0.f;
+      float col[12], btv;
+#pragma unroll
+      for (int m = 0; m < 12; ++m) col[m] = sm.Mf[H - 1][m][rn];
+      btv = sm.u.itv.bt[H - 1][r6];
+#pragma unroll 1
+      for (int i = H - 1; i >= 0; --i) {
+        // the operands of the next step are requested before this step's chain starts
+        const int ip = i > 0 ? i - 1 : 0;
+        float coln[12];
+#pragma unroll
+        for (int m = 0; m < 12; ++m) coln[m] = sm.Mf[ip][m][rn];
+        const float btn = sm.u.itv.bt[ip][r6];
+        BMPC_SCHED_BARRIER();
+        const float uu = rn >= 6 ? p - btv : p;
+        if (rn >= 6) sm.u.itv.gs[i][r6] = uu;     // g_i (same value from the four rows and the clone lanes)
+        float a0 = p, a1 = 0.f, a2 = 0.f;
+        a0 = fmaf(col[0], row_bcast<0>(uu), a0);  a1 = fmaf(col[1], row_bcast<1>(uu), a1);  a2 = fmaf(col[2], row_bcast<2>(uu), a2);
+        a0 = fmaf(col[3], row_bcast<3>(uu), a0);  a1 = fmaf(col[4], row_bcast<4>(uu), a1);  a2 = fmaf(col[5], row_bcast<5>(uu), a2);
+        a0 = fmaf(col[6], row_bcast<6>(uu), a0);  a1 = fmaf(col[7], row_bcast<7>(uu), a1);  a2 = fmaf(col[8], row_bcast<8>(uu), a2);
+        a0 = fmaf(col[9], row_bcast<9>(uu), a0);  a1 = fmaf(col[10], row_bcast<10>(uu), a1); a2 = fmaf(col[11], row_bcast<11>(uu), a2);
+        p = a0 + (a1 + a2);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) col[m] = coln[m];
+        btv = btn;
+      }
+      BMPC_WAVE_SYNC();
+      // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value)
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const int j = js[s];
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc = fmaf(sm.Sinv[j][c][m], sm.u.itv.gs[j][m], acc);
+        sm.u.itv.wv[j][c] = acc;
+      }
+      BMPC_WAVE_SYNC();
+      float x = 0.f;
+      float rowm[12], wvv;
+#pragma unroll
+      for (int m = 0; m < 12; m += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&sm.Mf[0][rn][m]);
+        rowm[m] = v.x; rowm[m + 1] = v.y; rowm[m + 2] = v.z; rowm[m + 3] = v.w;
+      }
+      wvv = sm.u.itv.wv[0][r6];
+#pragma unroll 1
+      for (int i = 0; i < H; ++i) {
+        const int ip = i + 1 < H ? i + 1 : i;
+        float rown[12];
+#pragma unroll
+        for (int m = 0; m < 12; m += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(&sm.Mf[ip][rn][m]);
+          rown[m] = v.x; rown[m + 1] = v.y; rown[m + 2] = v.z; rown[m + 3] = v.w;
+        }
+        const float wvn = sm.u.itv.wv[ip][r6];
+        BMPC_SCHED_BARRIER();
+        float a0 = rn >= 6 ? -wvv : 0.f, a1 = 0.f, a2 = 0.f;
+        a0 = fmaf(rowm[0], row_bcast<0>(x), a0);  a1 = fmaf(rowm[1], row_bcast<1>(x), a1);  a2 = fmaf(rowm[2], row_bcast<2>(x), a2);
+        a0 = fmaf(rowm[3], row_bcast<3>(x), a0);  a1 = fmaf(rowm[4], row_bcast<4>(x), a1);  a2 = fmaf(rowm[5], row_bcast<5>(x), a2);
+        a0 = fmaf(rowm[6], row_bcast<6>(x), a0);  a1 = fmaf(rowm[7], row_bcast<7>(x), a1);  a2 = fmaf(rowm[8], row_bcast<8>(x), a2);
+        a0 = fmaf(rowm[9], row_bcast<9>(x), a0);  a1 = fmaf(rowm[10], row_bcast<10>(x), a1); a2 = fmaf(rowm[11], row_bcast<11>(x), a2);
+        const float inc = a0 + (a1 + a2);       // rows 0..5: (C xi2)[rn];  rows 6..11: the acceleration a_i[rn - 6]
+        if (rn >= 6) sm.u.itv.av[i][r6] = inc;
+        x += inc;
+        sm.u.itv.xi[i][rn] = x;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) rowm[m] = rown[m];
+        wvv = wvn;
+      }
+    }
+    BMPC_WAVE_SYNC();
+    BMPC_SSTAMP(3)
+    // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
+    const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // wave-uniform
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      float gm[6];
+      f2 lg[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        gm[i] = sm.u.itv.av[j][i];
+        lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
+      }
+      const float xin = sm.u.itv.xi[j][n];
+      BMPC_SCHED_BARRIER();
+      f2 dd = ddk[s];                           // {d_f[c], (G_f d_f)[c]}
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(lg[i], f2{gm[i], gm[i]}, dd);
+      const RT xto = xo[s] - (RT)dd.x;
+      const RT ztg = axg[s] - (RT)dd.y;
+      const RT ztb = xto;
+      RT st_pb, st_pg;
+      {
+        const RT zr = alpha * ztb + (1 - alpha) * zb[s];
+        const RT cand = zr + yb[s] * irvb[s];
+        const RT zn = fmin(fmax(cand, widen(lb[s])), widen(ub[s]));
+        yb[s] += widen(rvb[s]) * (zr - zn);
+        zb[s] = zn;
+        st_pb = ztb - zn;
+      }
+      {
+        const RT zr = alpha * ztg + (1 - alpha) * zg[s];
+        const RT cand = zr + yg[s] * irvg[s];
+        const RT zn = fmin(cand, (RT)0);
+        yg[s] += widen(rvg[s]) * (zr - zn);
+        zg[s] = zn;
+        st_pg = ztg - zn;
+      }
+      if (check_now && sreal[s]) {
+        rp = fmaxf(rp, fmaxf(fabsf((float)st_pb), fabsf((float)st_pg)));
+        nz = fmaxf(nz, fmaxf(fabsf((float)xto), fabsf((float)ztg)));
+        rs = fmaxf(rs, fabsf((float)(xto - xo[s])));
+        // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
+        nx = fmaxf(nx, (xto == xto) ? fabsf((float)xto) : __builtin_inff());
+      }
+      xo[s] = alpha * xto + (1 - alpha) * xo[s];
+      axg[s] = alpha * ztg + (1 - alpha) * axg[s];
+      // W x~ = W x - gamma exactly, so the tracking error follows the state response of the solve (f32 increment: it
+      // vanishes with the step; rebuilt exactly in f64 every REFRESH_ITERS iterations and before leaving)
+      err[s] -= alpha * (RT)xin;
+    }
+    ++it;
+    BMPC_SSTAMP(4)
+    // --- stopping test and penalty re-classification (wave-uniform decisions; one wave: reductions by DPP alone)
+    const bool adapt_now = (it == next_adapt);
+    if (adapt_now) next_adapt += P.adapt_every;
+    const bool adapt_do = adapt_now && nfac <= P.max_refactor;
+    auto reclassify = [&](int s, float& nb, float& ng) {
+      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
+      const bool actb = (zb[s] <= (RT)lb[s] || zb[s] >= (RT)ub[s]) && yb[s] != (RT)0;
+      const bool actg = (zg[s] >= (RT)0) && yg[s] != (RT)0;
+      const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+      nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kap, hib) : fmaxf(rvb[s] / kap, P.rho_lo));
+      ng = actg ? fminf(rvg[s] * kap, hig) : fmaxf(rvg[s] / kap, P.rho_lo);
+    };
+    if (check_now || adapt_do) {
+      float chg = 0.f;
+      if (adapt_do) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+          float nb, ng;
+          reclassify(s, nb, ng);
+          chg = (sreal[s] && ((nb != rvb[s]) | (ng != rvg[s]))) ? 1.f : chg;
+        }
+      }
+      float v5[5] = {rp, rs, nz, nx, chg};
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
+      if (check_now) {
+        res_p = v5[0];
+        res_s = v5[1];
+        const float tol_p = P.eps_pri * fmaxf(1.f, v5[2]), tol_s = P.eps_dua * fmaxf(1.f, v5[3]);
+        const bool bad = !(v5[0] == v5[0]) || !(v5[1] == v5[1]) || !(v5[3] < 3.0e38f);
+        const bool done = v5[0] <= tol_p && v5[1] <= tol_s;
+        const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
+        next_check += far ? 2 * check_every : check_every;
+        const bool rebuild = it >= next_refresh;
+        if (rebuild) next_refresh = it + REFRESH_ITERS;
+        if (bad || done || it == P.max_iter || rebuild) refresh();
+        if (bad) { status = 2; break; }
+        if (done) { status = 0; break; }
+      }
+      if (adapt_do && v5[4] > 0.f) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+          float nb, ng;
+          reclassify(s, nb, ng);
+          rvb[s] = nb; rvg[s] = ng;
+          irvb[s] = (RT)1 / (RT)nb; irvg[s] = (RT)1 / (RT)ng;
+        }
+        need_factor = true;
+      }
+    }
+    BMPC_SSTAMP(5)
+    BMPC_DRAIN_LDS();
+  }
+  if (warm.buf && warm.store) {
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      if (!(sreal[s] && lane_real)) continue;
+      double* dst = warm.buf + (((size_t)inst * HS + js[s]) * 12 + n) * 6;
+      dst[0] = xo[s]; dst[1] = zb[s]; dst[2] = zg[s]; dst[3] = yb[s]; dst[4] = yg[s];
+      dst[5] = __hiloint2double(__float_as_int(rvg[s]), __float_as_int(rvb[s]));
+    }
+  }
+
+  // ------------------------------------------------------------------ F. outputs (REF:300-304)
+  // every way out of the loop rebuilt err exactly at its last stopping test: X = x_ref + err = s0 + (err - e0)
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    if (!(sreal[s] && lane_real)) continue;
+    const int j = js[s];
+    float* uo = controls + ((size_t)inst * H + j) * 12;
+    const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
+    uo[pos] = (float)xo[s];
+    if (states) {
+      float* so = states + ((size_t)inst * H + j) * 13;
+      so[n] = (float)(sm.s0[j][n] + (err[s] - e0[s]));
+      if (n == 0) so[12] = 1.0f;
+    }
+  }
+  if (PROF && dbg.prof && l == 0) {
+    long long* pr = dbg.prof + (size_t)inst * 16;
+    pr[0] = t_setup; pr[1] = t_blocks; pr[2] = t_ric; pr[3] = clock64() - t_start; pr[4] = it; pr[5] = nfac;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pr[8 + k] = t_ph[k];
+  }
+  if (l == 0) {
+    if (iters_out) iters_out[inst] = it;
+    if (status_out) status_out[inst] = status;
+    if (nfactor_out) nfactor_out[inst] = nfac;
+    if (resid_out) { resid_out[2 * inst] = res_p; resid_out[2 * inst + 1] = res_s; }
+  }
+#undef BMPC_SSTAMP
+}
+
+#define BMPC_STAGE_ARGS                                                                                            \
+  const DevParams P, const int B, const float* __restrict__ x_fb, const float* __restrict__ foot,                  \
+      const uint8_t* __restrict__ contact, const int32_t* __restrict__ phase, const float* __restrict__ x_cmd,     \
+      const float* __restrict__ mu_in, float* __restrict__ controls, float* __restrict__ states,                   \
+      int32_t* __restrict__ iters_out, float* __restrict__ resid_out, int32_t* __restrict__ status_out,            \
+      int32_t* __restrict__ nfactor_out, const DebugOut dbg, const WarmArgs warm
+// waves per SIMD the register allocation aims at: what the LDS image of an instance leaves room for
+template <int NP> struct StageOcc { static constexpr int WPE = NP <= 2 ? 3 : (NP <= 4 ? 2 : 1); };
+template <int NP>
+__global__ void __launch_bounds__(64, StageOcc<NP>::WPE) stage_kernel(BMPC_STAGE_ARGS) {
+  stage_body<NP, false>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
+                        nfactor_out, dbg, warm);
+}
+template <int NP>
+__global__ void __launch_bounds__(64, StageOcc<NP>::WPE) stage_kernel_prof(BMPC_STAGE_ARGS) {
+  stage_body<NP, true>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
+                       nfactor_out, dbg, warm);
+}
+#undef BMPC_STAGE_ARGS
+
+}  // namespace bmpc

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 5
+#define BMPC_ABI_VERSION 6
 
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
@@ -36,6 +36,18 @@ enum bmpc_status {
   BMPC_ERR_NO_DEVICE = -2,   /* no usable HIP device: the library never falls back to the CPU */
   BMPC_ERR_HIP = -3,         /* a HIP runtime call failed */
   BMPC_ERR_ALLOC = -4
+};
+
+/* bmpc_params.path: which kernel family solves (REF:203-216 keeps the stage structure that BMPC_PATH_STAGE exploits) */
+enum bmpc_path {
+  BMPC_PATH_AUTO = 0,
+  BMPC_PATH_DENSE = 1,
+  BMPC_PATH_STAGE = 2
+};
+
+enum bmpc_penalty_mode {
+  BMPC_PENALTY_SCALED = 0,
+  BMPC_PENALTY_ABSOLUTE = 1
 };
 
 /* per-instance status[] values written by the solver */
@@ -68,7 +80,7 @@ typedef struct bmpc_params {
   double f_max[3], f_min[3];     /* REF:45-46 */
   double tau_max[3], tau_min[3]; /* REF:47-48 */
   /* solver (ADMM with active-set adaptive penalties) */
-  double rho;                /* initial penalty on every row (default 0.03; 0.045 at h = 20) */
+  double rho;                /* initial penalty on every row (default 0.03; 0.045 at h >= 20); see penalty_mode */
   double rho_eq_scale;       /* multiplier for rows with l == u (pinned variables) */
   double rho_lo;             /* floor of the per-row penalties */
   double rho_hi_f;           /* ceiling for force-like rows (force box, friction) */
@@ -86,6 +98,13 @@ typedef struct bmpc_params {
                                 period follows the cost of a factorisation relative to an iteration) */
   int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached) */
   int32_t warm_adapt_start;  /* first re-classification of a warm-started solve (bmpc_set_warm_start); 0 = adapt_start */
+  int32_t path;              /* kernel family: BMPC_PATH_AUTO (default: the faster one for h), BMPC_PATH_DENSE (explicit
+                                6h x 6h inverse in registers; h <= 20) or BMPC_PATH_STAGE (stage-structured Riccati solve,
+                                O(h) work and state; every supported h).  Same optimum, same outer method. */
+  int32_t penalty_mode;      /* BMPC_PENALTY_SCALED (default): rho, rho_lo, rho_hi_*, rho_eq are the values at the reference
+                                problem (REF:22-48 defaults, h = 10) and are scaled by the curvature of the problem at
+                                hand relative to it -- stiff end (Q, dt, m, I, h) for the ceilings and rho_eq, 2 R for the
+                                floor, their geometric mean for the start; BMPC_PENALTY_ABSOLUTE: taken as they are */
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
   double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
   double swingHeight;        /* REF:32 */
@@ -97,8 +116,15 @@ typedef struct bmpc_handle_s* bmpc_handle;
 /* Library / ABI identification. */
 int bmpc_abi_version(void);
 const char* bmpc_last_error(void);
-/* 1 if a kernel is built for this horizon, else 0. */
+/* 1 if a kernel is built for this horizon, else 0: every even h in [8, 40] (REF:24: the horizon is a plain field of MPC).
+ * bmpc_supported_horizon_path(h, path) asks for one kernel family (dense: h <= 20). */
 int bmpc_supported_horizon(int h);
+int bmpc_supported_horizon_path(int h, int path);
+/* The penalties the kernels will use for this parameter block after the scaling of `penalty_mode`:
+ * out5 = {rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m}.  Host arithmetic only (no device needed). */
+int bmpc_effective_penalties(const bmpc_params* params, double* out5);
+/* The kernel family a handle's solves run on (BMPC_PATH_DENSE or BMPC_PATH_STAGE; <0 on error). */
+int bmpc_solver_path(bmpc_handle h);
 /* Reference defaults (REF:22-48) and solver defaults for horizon h. */
 int bmpc_default_params(bmpc_params* p, int h);
 

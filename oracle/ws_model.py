@@ -193,7 +193,7 @@ def constraint_blocks(P, x_fb, contact, mu, dt_):
     return A, l, u
 
 
-def _factor(P, Gt, A, rv, Rblk, Wf, Nf, dtp, blk=None):
+def _factor(P, Gt, A, rv, Rblk, Wf, Nf, dtp, blk=None, ric=None):
     """Everything that depends on the per-row penalties rv: L, Na (block diagonal) and V (dense).
     blk: arithmetic of the 6x6 block algebra (default dtp); the dense sweep is always dtp."""
     B, h = rv.shape[0], P.h
@@ -204,12 +204,16 @@ def _factor(P, Gt, A, rv, Rblk, Wf, Nf, dtp, blk=None):
     Dinv = np.linalg.inv(D)
     E = np.einsum("bhfij,bhfjk,bhflk->bhil", Wf_, Dinv, Wf_)
     F = np.linalg.inv(E)
-    L = np.einsum("bhfij,bhfkj,bhkl->bhfil", Dinv, Wf_, F).astype(dtp)    # (B,h,2,6,6): D^-1 W' F
+    L = np.einsum("bhfij,bhfkj,bhkl->bhfil", Dinv, Wf_, F).astype(bt if getattr(P, "f64_L", False) else dtp)    # (B,h,2,6,6): D^-1 W' F
     Ka = np.einsum("bhfij,bhfik,bhfkl->bhjl", Nf_, D, Nf_)
     Kainv = np.linalg.inv(Ka)
-    Na = np.einsum("bhfij,bhjk,bhglk->bhfigl", Nf_, Kainv, Nf_).astype(dtp)  # (B,h,f,6,g,6)
-    K = Gt.astype(dtp).copy()
+    Na = np.einsum("bhfij,bhjk,bhglk->bhfigl", Nf_, Kainv, Nf_).astype(bt if getattr(P, "f64_Na", False) else dtp)  # (B,h,f,6,g,6)
     F32 = F.astype(dtp)
+    if ric is not None:
+        # stage-structured path: V is never formed, gamma = V beta is a Riccati solve
+        from . import riccati_model
+        return L, Na, riccati_model.factor(P, F32, ric[0], ric[1], dtp)
+    K = Gt.astype(dtp).copy()
     for j in range(h):
         K[:, 6 * j:6 * j + 6, 6 * j:6 * j + 6] += F32[:, j]
     V = np.linalg.inv(K).astype(dtp)
@@ -261,12 +265,14 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     Nf[:, :, 0] = np.eye(6, dtype=dtp)
     Nf[:, :, 1] = -np.eye(6, dtype=dtp)
     Nf[:, :, 1, 3:6, 0:3] = -_skew(r[:, :, 0] - r[:, :, 1])
-    fac = lambda rv_: _factor(P, Gt, A, rv_, Rblk, Wf, Nf, pdt, blk=(rdt if P.blocks_hi else pdt))
+    ric = (Iw_inv, Rinv) if getattr(P, "solver", "dense") == "riccati" else None
+    fac = lambda rv_: _factor(P, Gt, A, rv_, Rblk, Wf, Nf, pdt, blk=(rdt if P.blocks_hi else pdt), ric=ric)
     L, Na, V = fac(rv)
     n_factor = np.ones(B, int)
     next_adapt, gap = P.adapt_start, P.adapt_every
     cnt_act = np.zeros(rv.shape, int)
     cnt_len = 0
+    act_prev = None
     alpha = rdt.type(P.alpha)
     x = np.zeros((B, h, 2, 6), rdt)
     z = np.zeros((B, h, 2, 12), rdt)
@@ -288,9 +294,13 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
         r_u = (np.einsum("bhfij,bhi->bhfj", Wr, gb) + Rr[None, None] * x
                + np.einsum("bhfri,bhfr->bhfi", Ar, y + rvr * (Ax - z)))
         # preconditioner (pdt): dx = K^-1 r = Na r + L V L' r
-        r32 = r_u.astype(pdt)
+        r32 = r_u.astype(rdt if getattr(P, "f64_r", False) else pdt)
         beta = np.einsum("bhfij,bhfi->bhj", L, r32).reshape(B, 6 * h)
-        gam = np.einsum("bij,bj->bi", V, beta).reshape(B, h, 6)
+        if ric is not None:
+            from . import riccati_model
+            gam = riccati_model.solve(V, beta.reshape(B, h, 6))[0]
+        else:
+            gam = np.einsum("bij,bj->bi", V, beta).reshape(B, h, 6)
         dx = np.einsum("bhfigl,bhgl->bhfi", Na, r32) + np.einsum("bhfil,bhl->bhfi", L, gam)
         xt = x - dx.astype(rdt)
         zt = np.einsum("bhfri,bhfi->bhfr", Ar, xt)
@@ -328,9 +338,18 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
                 # damping as in the kernel: sqrt(kappa) after 10 factorisations, its square root after 16
                 kap = np.where(n_factor <= 10, P.kappa, np.where(n_factor <= 16, P.kappa ** 0.5, P.kappa ** 0.25))
                 kap = kap.astype(dtp)[:, None, None, None]
-                up = np.minimum(rv * kap, hi)
-                dn = np.maximum(rv / kap, dt_(P.rho_lo))
+                rvc = np.clip(rv, dt_(P.rho_lo), hi)            # (rows coming back from the finishing penalties)
+                up = np.minimum(rvc * kap, hi)
+                dn = np.maximum(rvc / kap, dt_(P.rho_lo))
                 rnew = np.where(eq, rho_eq, np.where(act, up, dn)).astype(dtp)
+                fin = getattr(P, "finish", None)
+                if fin:
+                    # finishing move: an active set that did not change since the last re-classification is taken for
+                    # the final one and gets near-hard / near-free penalties
+                    same = (act == act_prev).reshape(B, -1).all(1) if act_prev is not None else np.zeros(B, bool)
+                    rfin = np.where(eq, rho_eq, np.where(act, hi * dt_(fin[1]), dt_(fin[0]))).astype(dtp)
+                    rnew = np.where(same[:, None, None, None], rfin, rnew)
+                    act_prev = act.copy()
             else:
                 rnew = np.where(eq, rho_eq, np.where(act, hi, dt_(P.rho_lo))).astype(dtp)
             cnt_act[:] = 0
@@ -346,7 +365,8 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     states = rollout(P, x_fb, Iw_inv, Rinv, wr, dt_)
     info = dict(iters=it_done, n_factor=n_factor)
     if return_debug:
-        info.update(x_ref=x_ref, foot_ref=foot_ref, Gt=Gt, qt=qt, s=s, V=V, Iw_inv=Iw_inv, Rinv=Rinv, r=r)
+        info.update(x_ref=x_ref, foot_ref=foot_ref, Gt=Gt, qt=qt, s=s, V=V, Iw_inv=Iw_inv, Rinv=Rinv, r=r,
+                    rv=rv, x=x, z=z, y=y, l=l, u=u, A=A)
     return states, ctrl, info
 
 

@@ -109,7 +109,22 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
 #define BMPC_OPAQUE(x) do { } while (0)
 #define BMPC_SCHED_BARRIER() do { } while (0)
 
+static float g_bc[1024];
+namespace bmpc {
+// value of lane N of the own row of 16 lanes (DPP row_newbcast on the GPU); all lanes of the wave call
+template <int N>
+static inline float row_bcast(float v) {
+  std::barrier<>& wb = *g_wbar[threadIdx.x >> 6];
+  g_bc[threadIdx.x] = v;
+  wb.arrive_and_wait();
+  const float r = g_bc[(threadIdx.x & ~15) + N];
+  wb.arrive_and_wait();
+  return r;
+}
+}  // namespace bmpc
+
 #include "../../biped_mpc_py_amd/csrc/bmpc_kernels.hip"
+#include "../../biped_mpc_py_amd/csrc/bmpc_stage.hip"
 #include "bmpc.h"
 
 namespace {
@@ -138,6 +153,26 @@ void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot
   }
 }
 
+template <int NP>
+void run_stage(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+               const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states, int32_t* iters,
+               float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg, const bmpc::WarmArgs& warm) {
+  for (int b = 0; b < B; ++b) {
+    std::barrier<> bar(64), wbar(64);
+    g_bar = &bar;
+    g_wbar[0] = &wbar;
+    for (int p = 0; p < 32; ++p) g_pair[p].store(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 64; ++t)
+      th.emplace_back([&, t]() {
+        threadIdx.x = t;
+        blockIdx.x = b;
+        bmpc::stage_kernel<NP>(P, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
+      });
+    for (auto& x : th) x.join();
+  }
+}
+
 // the same mapping as make_dev_params in csrc/bmpc_capi.hip (kept in step by tests/test_emu.py: identical outputs)
 bool inv3(const double* a, double* o) {
   const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
@@ -153,6 +188,8 @@ bool inv3(const double* a, double* o) {
 }  // namespace
 
 extern "C" int bmpc_emu_threads(int h) { return h == 10 ? bmpc::Dims<10>::NT : (h == 16 ? bmpc::Dims<16>::NT : (h == 20 ? bmpc::Dims<20>::NT : -1)); }
+// doubles per instance of the warm-start buffer of the stage path
+extern "C" int bmpc_emu_stage_warm(int h) { return 5 * ((h + 4) / 5) * 12 * 6; }
 
 extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                               const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
@@ -176,6 +213,15 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   bmpc::DebugOut dbg = {dbg_x_ref, dbg_foot_ref, dbg_Gt, dbg_qt, nullptr, assemble_only};
   bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta, p->warm_adapt_start};
   if (const char* e = std::getenv("BMPC_EMU_POISON")) g_poison = std::atoi(e);
+  if (p->path == BMPC_PATH_STAGE) {
+    switch ((p->h + 4) / 5) {
+#define EMU_CASE(NN) case NN: run_stage<NN>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
+      EMU_CASE(2) EMU_CASE(3) EMU_CASE(4) EMU_CASE(5) EMU_CASE(6) EMU_CASE(7) EMU_CASE(8)
+#undef EMU_CASE
+      default: return -1;
+    }
+    return 0;
+  }
   switch (p->h) {
     case 10: run_h<10>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
     case 16: run_h<16>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;

@@ -15,7 +15,7 @@ CLANG = os.environ.get("BMPC_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 def build(force=False):
     srcs = [os.path.join(HERE, "bmpc_emu.cpp"), os.path.join(ROOT, "biped_mpc_py_amd", "csrc", "bmpc_kernels.hip"),
-            os.path.join(ROOT, "include", "bmpc.h")]
+            os.path.join(ROOT, "biped_mpc_py_amd", "csrc", "bmpc_stage.hip"), os.path.join(ROOT, "include", "bmpc.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
         subprocess.check_call([CLANG, "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", "-D_GNU_SOURCE",
                                "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-x", "c++", srcs[0], "-o", SO])
@@ -36,6 +36,14 @@ def solve(cparams, x_fb, foot, contact, phase, x_cmd=None, mu=None, assemble_onl
     """Same marshalling as BatchSolver.solve / assemble.  Returns dict.  `warm`: None, or a float64 array
     (B, threads(h), 6) that receives the final solver state and, with warm_load, provides the start."""
     lib = C.CDLL(build())
+    # the emulation takes the penalties as they are: the scaling of `penalty_mode` is the library's host arithmetic
+    from biped_mpc_py_amd import _lib as _bl
+    eff = (C.c_double * 5)()
+    _bl.check(_bl.load().bmpc_effective_penalties(C.byref(cparams), eff))
+    cp2 = type(cparams)()
+    C.memmove(C.byref(cp2), C.byref(cparams), C.sizeof(cparams))
+    cp2.rho, cp2.rho_eq_scale, cp2.rho_lo, cp2.rho_hi_f, cp2.rho_hi_m, cp2.penalty_mode = eff[0], eff[1] / eff[0], eff[2], eff[3], eff[4], 1
+    cparams = cp2
     h = int(cparams.h)
     x_fb = np.ascontiguousarray(np.asarray(x_fb, np.float32).reshape(-1, 12))
     B = x_fb.shape[0]
