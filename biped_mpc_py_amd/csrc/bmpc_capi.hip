@@ -333,8 +333,10 @@ int bmpc_default_params(bmpc_params* p, int h) {
   // 21.5 at h = 20 (profiles/r02_cfg*_phase_cycles.txt).  Measured on MI355X (build_tmp-style A/B, round 2):
   // h = 16: period 20 from iteration 10 is 8 % faster than 10 / 10 (4.3 instead of 5.6 factorisations, 68 instead of
   // 53 iterations), h = 20: 20 / 20 is 12 % faster (4.8 instead of 6.8, 88 instead of 66); h = 10 is best at 10 / 10.
-  p->adapt_every = h <= 12 ? 10 : 20;
-  p->adapt_start = h < 20 ? 10 : 20;
+  // (h > 20 runs on the stage-structured kernels, where a factorisation costs 4-5 iterations instead of 15-20:
+  //  period 10 again; measured with tools/stage_probe.py)
+  p->adapt_every = (h <= 12 || h > 20) ? 10 : 20;
+  p->adapt_start = (h < 20 || h > 20) ? 10 : 20;
   p->warm_adapt_start = 5;                                            // (tools/warm_sweep.py)
   p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
   p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31

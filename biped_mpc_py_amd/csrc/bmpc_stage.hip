@@ -43,10 +43,47 @@ __device__ __forceinline__ float row_bcast(float v) {
 }
 #endif
 
+// acc + sum_m cf[m] * (value of u in lane m of the own DPP row), m = 0 .. 11: the step of the two sequential passes of a
+// stage solve.  A single wave issues one vector instruction per 4 cycles, so the latency of the chain IS its instruction
+// count: the broadcasts ride on the FMAs (v_fmac_f32_dpp: one instruction per term; the compiler does not fold
+// row_newbcast moves into the FMA by itself), three accumulators keep the FMAs independent of their neighbours.
+// Inline asm: the hazard recogniser does not look inside, so the two wait states a DPP read needs after the VALU write
+// of its source (u is produced right before) are written out.
+__device__ __forceinline__ float row_matvec12(float acc, float u, const float (&cf)[12]) {
+#ifdef BMPC_EMU
+  float a0 = acc, a1 = 0.f, a2 = 0.f;
+  a0 = fmaf(cf[0], row_bcast<0>(u), a0);  a1 = fmaf(cf[1], row_bcast<1>(u), a1);   a2 = fmaf(cf[2], row_bcast<2>(u), a2);
+  a0 = fmaf(cf[3], row_bcast<3>(u), a0);  a1 = fmaf(cf[4], row_bcast<4>(u), a1);   a2 = fmaf(cf[5], row_bcast<5>(u), a2);
+  a0 = fmaf(cf[6], row_bcast<6>(u), a0);  a1 = fmaf(cf[7], row_bcast<7>(u), a1);   a2 = fmaf(cf[8], row_bcast<8>(u), a2);
+  a0 = fmaf(cf[9], row_bcast<9>(u), a0);  a1 = fmaf(cf[10], row_bcast<10>(u), a1); a2 = fmaf(cf[11], row_bcast<11>(u), a2);
+  return a0 + (a1 + a2);
+#else
+  float a0 = acc, a1 = 0.f, a2 = 0.f;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %3, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %3, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %3, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %3, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %3, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %3, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %3, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %3, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %3, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %3, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %3, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %3, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+      : "+v"(a0), "+v"(a1), "+v"(a2)
+      : "v"(u), "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]), "v"(cf[8]),
+        "v"(cf[9]), "v"(cf[10]), "v"(cf[11]));
+  return a0 + (a1 + a2);
+#endif
+}
+
 template <int NP>
 struct alignas(16) StageSmem {
   static constexpr int HS = 5 * NP;            // step capacity
-  struct FootBlock { float d[HS][6][6][2]; };
+  struct FootBlock { float d[HS][6][6]; };
   // f64 6x6 scratch of the block algebra of ONE pass (5 steps), indexed by lane group
   struct Fac {
     double M0[5][6][6];        // D0 -> Ka^-1 D0 W_0^-1
@@ -58,32 +95,31 @@ struct alignas(16) StageSmem {
   struct Itv {
     RT wg[HS][2][6];           // y + rho (A x - z) on the general rows; x itself for the exact rebuild and the outputs
     RT lam[HS][12];            // adjoint of the tracking error (acceleration space), and the scans' exchange
-    alignas(16) float r32[HS][2][6];   // KKT residual, control space
-    alignas(16) float bt[HS][6];       // right-hand side of the stage solve (E^-T beta)
-    float gs[HS][6];           // g = p2 - bt of the backward pass
-    float wv[HS][6];           // Sinv g
-    float av[HS][6];           // accelerations a = E gamma of the solve
+    alignas(16) float r32[HS][2][6];   // KKT residual, control space; after P3 the step d of x
+    alignas(16) float bt[HS][6];       // right-hand side of the stage solve (E^-T beta); after the backward pass w = Sinv g
+    float gs[HS][8];           // g = p2 - bt of the backward pass (slot 6: dump for the lanes that hold no g)
+    float av[HS][8];           // accelerations a = E gamma of the solve (slot 6: dump)
     alignas(16) float xi[HS][12];      // state response Gam_t gamma
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5][12];            // group totals of the scans over the steps (double buffered)
-  // block-diagonal part of K^-1, pairs {factor, G_f x factor} (see bmpc_kernels.hip); L~ = L E^-1 (acceleration space)
+  // block-diagonal part of K^-1 (see bmpc_kernels.hip): L~ = L E^-1 (acceleration space), Kn = {Ka^-1, T Ka^-1}.
+  // (no G images as in the dense kernels: an instance's LDS decides how many instances share a CU, and the step d
+  //  is exchanged once per iteration instead)
   alignas(16) FootBlock LG[2];
   alignas(16) FootBlock KG[2];
-  // stage solve: forward matrix Mf_i = [[0, C_i], [-K_i]] (12 x 12; rows 6..11 = minus the Riccati gain), S_i^-1, Ft_i
+  // stage solve: forward matrix Mf_i = [[0, C_i], [-K_i]] (12 x 12; rows 6..11 = minus the Riccati gain) and S_i^-1.
+  // Until the recursion reaches step i, rows 6..8 of Mf_i hold the stage cost Ft_i (36 floats) of the block algebra.
   alignas(16) float Mf[HS][12][12];
   alignas(16) float Sinv[HS][6][6];
-  alignas(16) float Ft[HS][6][6];
   alignas(16) float Pm[12][12];   // Riccati recursion: cost-to-go
-  alignas(16) float Zm[12][12];   //                    Schur complement
+  alignas(16) float Zm[12][12];   //                    Schur complement (blocks 12, 22; Z11 replaces Pi11 in Pm)
   alignas(16) float Tm[6][6];     //                    S^-1 Ft
   float q2[12];                   // 2 Q
   // step data
   RT Iwi[HS][9];               // world inverse inertia
-  RT Iww[HS][9];               // world inertia
   RT Rv[HS][9];                // R_inv (REF:160-164)
   RT rr[HS][2][3];             // r_f = foot_ref - com_ref
-  RT s0[HS][12];               // free response
   float muf[HS][2];
   float rvg[HS][2][6];
   RT Gu[6][6];
@@ -152,6 +188,9 @@ stage_body(const DevParams& P, const int B,
   if (threadIdx.x == 0) std::memset(&sm, g_poison, sizeof(sm));
   BMPC_WAVE_SYNC();
 #endif
+  // For many passes per lane the scheduler would interleave all of them (every pass body is independent of the others)
+  // and run out of registers; a fence after every second pass keeps two in flight.
+#define BMPC_PASS_FENCE(s) do { if constexpr (NP > 4) { if (((s) & 1) == 1) BMPC_SCHED_BARRIER(); } } while (0)
   long long t_start = 0, t_setup = 0, t_blocks = 0, t_ric = 0, t_mark = 0;
   long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #define BMPC_SSTAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
@@ -288,14 +327,8 @@ stage_body(const DevParams& P, const int B,
       const RT tp = sp / cp;
       const RT Rv[9] = {cy / cp, sy / cp, 0, -sy, cy, 0, cy * tp, sy * tp, 1};             // REF:160-164 inverted
       if (lead) {
-        // world inertia Iw = Rot' I Rot as the inverse of Iwi (3x3 cofactors)
-        const RT c00 = Iwi[4] * Iwi[8] - Iwi[5] * Iwi[7], c01 = Iwi[5] * Iwi[6] - Iwi[3] * Iwi[8], c02 = Iwi[3] * Iwi[7] - Iwi[4] * Iwi[6];
-        const RT idet = (RT)1 / (Iwi[0] * c00 + Iwi[1] * c01 + Iwi[2] * c02);
-        const RT Iww[9] = {c00 * idet, (Iwi[2] * Iwi[7] - Iwi[1] * Iwi[8]) * idet, (Iwi[1] * Iwi[5] - Iwi[2] * Iwi[4]) * idet,
-                           c01 * idet, (Iwi[0] * Iwi[8] - Iwi[2] * Iwi[6]) * idet, (Iwi[2] * Iwi[3] - Iwi[0] * Iwi[5]) * idet,
-                           c02 * idet, (Iwi[1] * Iwi[6] - Iwi[0] * Iwi[7]) * idet, (Iwi[0] * Iwi[4] - Iwi[1] * Iwi[3]) * idet};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { sm.Iwi[jst][k] = Iwi[k]; sm.Iww[jst][k] = Iww[k]; sm.Rv[jst][k] = Rv[k]; }
+        for (int k = 0; k < 9; ++k) { sm.Iwi[jst][k] = Iwi[k]; sm.Rv[jst][k] = Rv[k]; }
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -321,7 +354,6 @@ stage_body(const DevParams& P, const int B,
     if (n >= 3 && n < 6) e += dt * j1 * (n == 3 ? xfb[9] : (n == 4 ? xfb[10] : xfb[11]));
     if (n == 5) e -= (RT)P.g * dt * dt * (RT)jg[s] * j1 / 2;
     if (n == 11) e -= (RT)P.g * dt * j1;
-    sm.s0[j][n] = e;
     e0[s] = e - e0[s];
     err[s] = e0[s];                            // x = 0
   }
@@ -412,9 +444,17 @@ stage_body(const DevParams& P, const int B,
       for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
         for (int a = 0; a < 3; ++a) rf[ft][a] = (float)sm.rr[j][ft][a];
-      double Ei[9];                              // E^-1 torque block: Iw / dt
+      double Ei[9];                              // E^-1 torque block: Iw / dt = (dt Iw^-1)^-1 (3x3 cofactors)
+      {
+        double w[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Ei[k] = sm.Iww[j][k] * idt;
+        for (int k = 0; k < 9; ++k) w[k] = sm.Iwi[j][k];
+        const double c00 = w[4] * w[8] - w[5] * w[7], c01 = w[5] * w[6] - w[3] * w[8], c02 = w[3] * w[7] - w[4] * w[6];
+        const double id = idt / (w[0] * c00 + w[1] * c01 + w[2] * c02);
+        Ei[0] = c00 * id; Ei[1] = (w[2] * w[7] - w[1] * w[8]) * id; Ei[2] = (w[1] * w[5] - w[2] * w[4]) * id;
+        Ei[3] = c01 * id; Ei[4] = (w[0] * w[8] - w[2] * w[6]) * id; Ei[5] = (w[2] * w[3] - w[0] * w[5]) * id;
+        Ei[6] = c02 * id; Ei[7] = (w[1] * w[6] - w[0] * w[7]) * id; Ei[8] = (w[0] * w[4] - w[1] * w[3]) * id;
+      }
       double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
       {
         const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
@@ -536,7 +576,7 @@ stage_body(const DevParams& P, const int B,
         if (hf == 0) {
 #pragma unroll
           for (int b = 0; b < 6; ++b) {
-            sm.LG[0].d[j][c][b][0] = (float)wE[b];
+            sm.LG[0].d[j][c][b] = (float)wE[b];
             sm.u.fac.M2[q][c][b] = wE[b];         // L~_0 rows for Ft
           }
         } else {
@@ -550,8 +590,8 @@ stage_body(const DevParams& P, const int B,
         row_times_mat6(urow, sm.u.fac.M2[q], fv64);     // Ft = U~ L~_0
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          sm.KG[0].d[j][c][b][0] = (float)ka[b];
-          sm.Ft[j][c][b] = (float)fv64[b];
+          sm.KG[0].d[j][c][b] = (float)ka[b];
+          sm.Mf[j][6 + c / 2][6 * (c % 2) + b] = (float)fv64[b];      // Ft[c][b], parked in rows 6..8 of Mf_j
         }
       }
       if (on1) {
@@ -560,42 +600,44 @@ stage_body(const DevParams& P, const int B,
         row_times_mat6(Trow, sm.u.fac.M1[q], sk);       // T Ka^-1
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          sm.LG[1].d[j][c][b][0] = (float)sl[b];
-          sm.KG[1].d[j][c][b][0] = (float)sk[b];
-        }
-      }
-      BMPC_WAVE_SYNC();
-      {                                          // rows c of G_f Kn_f and G_f L~_f (f32, from the stored f32 factors)
-        float gr[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) gr[b] = (float)sm.Gu[co][b] - ((b == 2 && co < 4) ? muf : 0.f);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          float gk = 0.f, gl = 0.f;
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            gk = fmaf(gr[b], sm.KG[f].d[j][b][i][0], gk);
-            gl = fmaf(gr[b], sm.LG[f].d[j][b][i][0], gl);
-          }
-          sm.KG[f].d[j][c][i][1] = gk;
-          sm.LG[f].d[j][c][i][1] = gl;
+          sm.LG[1].d[j][c][b] = (float)sl[b];
+          sm.KG[1].d[j][c][b] = (float)sk[b];
         }
       }
       BMPC_WAVE_SYNC();                         // the scratch is reused by the next pass
     }
     if constexpr (PROF) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
 
-    // ---- backward Riccati recursion over the steps (f32; oracle/riccati_model.py::factor).  Every lane works:
+    // ---- backward Riccati recursion over the steps (f32; oracle/riccati_model.py::factor).  Every lane works, three
+    // exchanges per step:
     //   R2  column jn of [M | Ft | I] solved against S = Ft + Pi22 (each lane its own LDL'): gain K, T = S^-1 Ft, S^-1
-    //   R3  Schur complement Z = Pi - Pi[:,2] S^-1 Pi[2,:], cancellation-free in the (., 2) blocks
-    //   R4  P11 = Z11, P12 = Z11 C + Z12          R5  P22 = C' P12 + Z12' C + Z22
+    //   R3  Schur complement Z = Pi - Pi[:,2] S^-1 Pi[2,:], cancellation-free in the (., 2) blocks: Z12 = Pi12 T, Z22 = Pi22 T
+    //   R4  P = A' Z A:  P11 = Z11, P12 = Z11 C + Z12, P22 = C' P12 + Z12' C + Z22
     {
       for (int e = l; e < 144; e += 64) sm.Pm[e / 12][e % 12] = 0.f;
       BMPC_WAVE_SYNC();
       const float dtf = (float)P.dt;
       const int jn = l < 24 ? l : 23;           // column of [M | Ft | I] this lane solves (lanes 24.. repeat column 23)
-      // C_i[a][k] (a, k < 3: dt Rinv_i; the translational block is dt I) is read from rows 0..5 of Mf_i
-#define BMPC_CI(a, k) sm.Mf[i][a][6 + (k)]
+      // R3: entry e = l and l + 64 of the 108 entries [Z11 | Z12 | Z22]: base + sum_m Lrow[m] Rcol[m]
+      int z_a[2], z_b[2], z_blk[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int e = (l + 64 * t) < 108 ? l + 64 * t : 107;
+        z_blk[t] = e / 36; z_a[t] = (e % 36) / 6; z_b[t] = e % 6;
+      }
+      // R4: lanes 0..35 own P22[k][k2], lanes 28..63 own P12[a2][k2b].  C_i = dt blkdiag(Rinv_i, I) enters through (row,
+      // coefficient) triples: column k < 3 of C has rows 0..2, column k >= 3 the single entry dt in row k.
+      const int pk = (l < 36 ? l : 35) / 6, pk2 = (l < 36 ? l : 35) % 6;
+      const int qa = (l >= 28 ? l - 28 : 0) / 6, qk = (l >= 28 ? l - 28 : 0) % 6;
+      auto ctriple = [&](int i, int k, int (&row)[3], float (&cf)[3]) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          row[t] = k < 3 ? t : k;
+          cf[t] = k < 3 ? sm.Mf[i][t][6 + k] : (t == 0 ? dtf : 0.f);
+        }
+      };
+      // Ft_i[a][b] sits in rows 6..8 of Mf_i until K_i overwrites them
+#define BMPC_FT(a, b) sm.Mf[i][6 + (6 * (a) + (b)) / 12][(6 * (a) + (b)) % 12]
 #pragma unroll 1
       for (int i = H - 1; i >= 0; --i) {
         // R2
@@ -604,104 +646,110 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
           for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b <= a; ++b) S[a][b] = sm.Ft[i][a][b] + sm.Pm[6 + a][6 + b] + (a == b ? sm.q2[6 + a] : 0.f);
-          if (jn < 6) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) rhs[m] = sm.Pm[6 + m][jn];
-          } else if (jn < 12) {
-            const int k = jn - 6;
-            const float qk = sm.q2[6 + k];
+            for (int b = 0; b <= a; ++b) S[a][b] = BMPC_FT(a, b) + sm.Pm[6 + a][6 + b] + (a == b ? sm.q2[6 + a] : 0.f);
+          {
+            // right-hand side: column jn of [Pi21 | Pi21 C + Pi22 | Ft | I], by address
+            const int k = jn < 12 ? (jn < 6 ? jn : jn - 6) : 0;
+            int row[3];
+            float cf[3];
+            ctriple(i, k, row, cf);
+            const float sel_m1 = jn < 6 ? 1.f : 0.f, sel_m2 = (jn >= 6 && jn < 12) ? 1.f : 0.f;
+            const float sel_ft = (jn >= 12 && jn < 18) ? 1.f : 0.f;
+            const int kf = (jn >= 12 && jn < 18) ? jn - 12 : 0, ki = jn >= 18 ? jn - 18 : -1;
+            const float qk2 = sm.q2[6 + k];
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-              float v = sm.Pm[6 + m][6 + k] + (m == k ? qk : 0.f);
-              if (k < 3) v += sm.Pm[6 + m][0] * BMPC_CI(0, k) + sm.Pm[6 + m][1] * BMPC_CI(1, k) + sm.Pm[6 + m][2] * BMPC_CI(2, k);
-              else v += dtf * sm.Pm[6 + m][k];
-              rhs[m] = v;
+              const float p21 = sm.Pm[6 + m][k];                       // Pi21[m][k]
+              const float p22 = sm.Pm[6 + m][6 + k] + (m == k ? qk2 : 0.f);
+              const float pc = sm.Pm[6 + m][row[0]] * cf[0] + sm.Pm[6 + m][row[1]] * cf[1] + sm.Pm[6 + m][row[2]] * cf[2];
+              const float ft = sm.Mf[i][6 + (6 * m + kf) / 12][(6 * m + kf) % 12];
+              rhs[m] = sel_m1 * p21 + sel_m2 * (pc + p22) + sel_ft * ft + (m == ki ? 1.f : 0.f);
             }
-          } else if (jn < 18) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) rhs[m] = sm.Ft[i][m][jn - 12];
-          } else {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) rhs[m] = (m == jn - 18) ? 1.f : 0.f;
           }
+          BMPC_WAVE_SYNC();                       // Ft_i consumed by every lane before K_i lands on it
           ldl6_solve(S, rhs, x);
-          if (jn < 12) {
+          // K -> rows 6..11 of Mf_i (negated), T -> Tm, S^-1 -> Sinv_i: one store address per lane
+          float* dst = jn < 12 ? &sm.Mf[i][6][jn] : (jn < 18 ? &sm.Tm[0][jn - 12] : &sm.Sinv[i][0][jn - 18]);
+          const int stride = jn < 12 ? 12 : 6;
+          const float sg = jn < 12 ? -1.f : 1.f;
 #pragma unroll
-            for (int m = 0; m < 6; ++m) sm.Mf[i][6 + m][jn] = -x[m];
-          } else if (jn < 18) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) sm.Tm[m][jn - 12] = x[m];
-          } else {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) sm.Sinv[i][m][jn - 18] = x[m];
-          }
+          for (int m = 0; m < 6; ++m) dst[m * stride] = sg * x[m];
         }
         BMPC_WAVE_SYNC();
-        // R3: entries 0..35 Z11, 36..71 Z12, 72..107 Z22 (Z11, Z22 symmetrised)
+        // R3 (Z11 and Z22 are symmetrised: both lanes of a mirrored pair of entries form the same two sums, so the
+        // cost-to-go stays exactly symmetric over the h steps -- without it the f32 asymmetry grows with the horizon
+        // and a few h = 40 instances in 4096 lose their convergence)
         {
-          auto zentry = [&](int e) {
-            const int blk = e / 36, a = (e % 36) / 6, b = e % 6;
-            if (blk == 0) {
-              // Z11[a][b] = Pi11[a][b] + sum_m Pi12[a][m] Mf[6 + m][b]   (rows 6.. of Mf are -K)
-              const float qd = a == b ? sm.q2[a] : 0.f;
-              float v1 = sm.Pm[a][b] + qd, v2 = sm.Pm[b][a] + qd;
+          float zv[2];
 #pragma unroll
-              for (int m = 0; m < 6; ++m) {
-                v1 = fmaf(sm.Pm[a][6 + m], sm.Mf[i][6 + m][b], v1);
-                v2 = fmaf(sm.Pm[b][6 + m], sm.Mf[i][6 + m][a], v2);
-              }
-              sm.Zm[a][b] = 0.5f * (v1 + v2);
-            } else if (blk == 1) {
-              float v = 0.f;
+          for (int t = 0; t < 2; ++t) {
+            const int blk = z_blk[t], a = z_a[t], b = z_b[t];
+            const int rs = blk == 0 ? 12 : 6;
+            const float* rbase = blk == 0 ? &sm.Mf[i][6][0] : &sm.Tm[0][0];
+            const int ro = blk == 2 ? 6 : 0;
+            const float qa2 = sm.q2[ro + a], qb2 = sm.q2[ro + b];
+            const float* lra = &sm.Pm[ro + a][6];
+            const float* lrb = &sm.Pm[ro + b][6];
+            float v1 = blk == 0 ? sm.Pm[a][b] + (a == b ? qa2 : 0.f) : 0.f;
+            float v2 = blk == 0 ? sm.Pm[b][a] + (a == b ? qa2 : 0.f) : 0.f;
 #pragma unroll
-              for (int m = 0; m < 6; ++m) v = fmaf(sm.Pm[a][6 + m], sm.Tm[m][b], v);
-              sm.Zm[a][6 + b] = v;
-              sm.Zm[6 + b][a] = v;
-            } else {
-              const float qa = sm.q2[6 + a], qb = sm.q2[6 + b];
-              float v1 = 0.f, v2 = 0.f;
-#pragma unroll
-              for (int m = 0; m < 6; ++m) {
-                v1 = fmaf(sm.Pm[6 + a][6 + m] + (a == m ? qa : 0.f), sm.Tm[m][b], v1);
-                v2 = fmaf(sm.Pm[6 + b][6 + m] + (b == m ? qb : 0.f), sm.Tm[m][a], v2);
-              }
-              sm.Zm[6 + a][6 + b] = 0.5f * (v1 + v2);
+            for (int m = 0; m < 6; ++m) {
+              v1 = fmaf(lra[m] + ((blk == 2 && m == a) ? qa2 : 0.f), rbase[m * rs + b], v1);
+              v2 = fmaf(lrb[m] + ((blk == 2 && m == b) ? qb2 : 0.f), rbase[m * rs + a], v2);
             }
-          };
-          zentry(l);
-          if (l + 64 < 108) zentry(l + 64);
+            zv[t] = blk == 1 ? v1 : 0.5f * (v1 + v2);
+          }
+          BMPC_WAVE_SYNC();                       // (emulation: Z11 replaces Pi11 in place, all reads first)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int blk = z_blk[t], a = z_a[t], b = z_b[t];
+            float* d1 = blk == 0 ? &sm.Pm[a][b] : (blk == 1 ? &sm.Zm[a][6 + b] : &sm.Zm[6 + a][6 + b]);
+            if (t == 0 || l + 64 < 108) *d1 = zv[t];
+          }
         }
         BMPC_WAVE_SYNC();
-        // R4: P11 = Z11 (lanes 0..35), P12 = Z11 C + Z12 (lanes 28..63)
+        // R4
         {
-          if (l < 36) {
-            const int a = l / 6, b = l % 6;
-            sm.Pm[a][b] = sm.Zm[a][b];
+          float p22 = 0.f, p12 = 0.f;
+          {
+            int ra[3], rb[3];
+            float ca[3], cb[3];
+            ctriple(i, pk, ra, ca);
+            ctriple(i, pk2, rb, cb);
+            // entry (pk, pk2) and its mirror, averaged
+            float v = sm.Zm[6 + pk][6 + pk2], w = sm.Zm[6 + pk2][6 + pk];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              float q12 = sm.Zm[ra[t]][6 + pk2];                       // P12[ra[t]][pk2] = Z12 + (Z11 C)
+              float r12 = sm.Zm[rb[t]][6 + pk];                        // P12[rb[t]][pk]
+#pragma unroll
+              for (int u = 0; u < 3; ++u) {
+                q12 = fmaf(sm.Pm[ra[t]][rb[u]], cb[u], q12);
+                r12 = fmaf(sm.Pm[rb[t]][ra[u]], ca[u], r12);
+              }
+              v = fmaf(ca[t], q12, v);
+              v = fmaf(sm.Zm[rb[t]][6 + pk], cb[t], v);                // (Z12' C)[pk][pk2]
+              w = fmaf(cb[t], r12, w);
+              w = fmaf(sm.Zm[ra[t]][6 + pk2], ca[t], w);
+            }
+            p22 = 0.5f * (v + w);
           }
-          if (l >= 28) {
-            const int e2 = l - 28, a2 = e2 / 6, k = e2 % 6;
-            float v = sm.Zm[a2][6 + k];
-            if (k < 3) v += sm.Zm[a2][0] * BMPC_CI(0, k) + sm.Zm[a2][1] * BMPC_CI(1, k) + sm.Zm[a2][2] * BMPC_CI(2, k);
-            else v += dtf * sm.Zm[a2][k];
-            sm.Pm[a2][6 + k] = v;
-            sm.Pm[6 + k][a2] = v;
+          {
+            int rb[3];
+            float cb[3];
+            ctriple(i, qk, rb, cb);
+            float v = sm.Zm[qa][6 + qk];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v = fmaf(sm.Pm[qa][rb[u]], cb[u], v);
+            p12 = v;
           }
-        }
-        BMPC_WAVE_SYNC();
-        // R5: P22[k][k2] = (C' P12)[k][k2] + (Z12' C)[k][k2] + Z22[k][k2]
-        if (l < 36) {
-          const int k = l / 6, k2 = l % 6;
-          float v = sm.Zm[6 + k][6 + k2];
-          if (k < 3) v += BMPC_CI(0, k) * sm.Pm[0][6 + k2] + BMPC_CI(1, k) * sm.Pm[1][6 + k2] + BMPC_CI(2, k) * sm.Pm[2][6 + k2];
-          else v += dtf * sm.Pm[k][6 + k2];
-          if (k2 < 3) v += sm.Zm[0][6 + k] * BMPC_CI(0, k2) + sm.Zm[1][6 + k] * BMPC_CI(1, k2) + sm.Zm[2][6 + k] * BMPC_CI(2, k2);
-          else v += dtf * sm.Zm[k2][6 + k];
-          sm.Pm[6 + k][6 + k2] = v;
+          BMPC_WAVE_SYNC();                       // (emulation: all reads of Pm / Zm before the stores)
+          if (l < 36) sm.Pm[6 + pk][6 + pk2] = p22;
+          if (l >= 28) { sm.Pm[qa][6 + qk] = p12; sm.Pm[6 + qk][qa] = p12; }
         }
         BMPC_WAVE_SYNC();
       }
-#undef BMPC_CI
+#undef BMPC_FT
     }
     if constexpr (PROF) t_ric += clock64() - t_mark;
   };
@@ -765,6 +813,7 @@ stage_body(const DevParams& P, const int B,
         acc = dt * (sm.Iwi[j][3 * k] * tau[0] + sm.Iwi[j][3 * k + 1] * tau[1] + sm.Iwi[j][3 * k + 2] * tau[2]);
       }
       v2[s] = acc;
+      BMPC_PASS_FENCE(s);
     }
     prefix_incl(v2);                            // (w, v) part of the state response (zero for n < 6)
     // (e, p) part: sum_{i <= j} C_i xi2_{i-1}: the lanes n < 6 need xi2 of the step before, other coordinates
@@ -853,6 +902,7 @@ stage_body(const DevParams& P, const int B,
           d = dt * (sm.Rv[j][k] * sm.u.itv.lam[j][0] + sm.Rv[j][3 + k] * sm.u.itv.lam[j][1] + sm.Rv[j][6 + k] * sm.u.itv.lam[j][2]);
         }
         cpl[s] = d;
+        BMPC_PASS_FENCE(s);
       }
       suffix_excl(cpl);
 #pragma unroll
@@ -898,18 +948,18 @@ stage_body(const DevParams& P, const int B,
         r += widen(cmu[s]) * ((wq[0] + wq[1]) + (wq[2] + wq[3]));
         const RT wt = g1 * rx0 - g2 * rx1 + gsel;
         sm.u.itv.r32[j][f][c] = (float)(r + wt);
+        BMPC_PASS_FENCE(s);
       }
     }
     BMPC_WAVE_SYNC();
     BMPC_SSTAMP(1)
     // --- P3: right-hand side of the stage solve bt = L~' r (own foot's part, summed over the pair), and the
     //     null-space part of the step: t = N' r = r_0 - T' r_1;  foot 0 gets Ka^-1 t, foot 1 -(T Ka^-1) t
-    f2 ddk[NP];
+    float ddk[NP];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       const int j = js[s];
-      float rj[2][6], lcol[6];
-      f2 kg[6];
+      float rj[2][6], lcol[6], kg[6];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -919,8 +969,8 @@ stage_body(const DevParams& P, const int B,
         }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        lcol[i] = sm.LG[f].d[j][i][c][0];
-        kg[i] = *reinterpret_cast<const f2*>(&sm.KG[f].d[j][c][i][0]);
+        lcol[i] = sm.LG[f].d[j][i][c];
+        kg[i] = sm.KG[f].d[j][c][i];
       }
       const float d0 = (float)sm.rr[j][0][0] - (float)sm.rr[j][1][0], d1 = (float)sm.rr[j][0][1] - (float)sm.rr[j][1][1],
                   d2 = (float)sm.rr[j][0][2] - (float)sm.rr[j][1][2];
@@ -937,10 +987,11 @@ stage_body(const DevParams& P, const int B,
       tn[3] = rj[0][3] - rj[1][3];
       tn[4] = rj[0][4] - rj[1][4];
       tn[5] = rj[0][5] - rj[1][5];
-      f2 dd = {0.f, 0.f};
+      float dd = 0.f;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(kg[i], f2{tn[i], tn[i]}, dd);
+      for (int i = 0; i < 6; ++i) dd = fmaf(kg[i], tn[i], dd);
       ddk[s] = f == 1 ? -dd : dd;
+      BMPC_PASS_FENCE(s);
     }
     BMPC_WAVE_SYNC();
     BMPC_SSTAMP(2)
@@ -948,97 +999,135 @@ stage_body(const DevParams& P, const int B,
     //     then w = Sinv g in parallel; forward pass: xi <- xi + Mf_i xi - [0; w_i]  (a_i = -K_i xi_{i-1} - w_i).
     //     One state coordinate per lane of a DPP row, operands by row broadcast: no LDS round trip in the chain.
     {
-      const int r6 = rn >= 6 ? rn - 6 : 0;
+      const int r6 = rn >= 6 ? rn - 6 : 0;      // component of bt / w the lane reads (0 for the lanes that read none)
+      const int d6 = rn >= 6 ? rn - 6 : 6;      // component of g / a the lane writes (6: the dump slot)
+      const float sel = rn >= 6 ? 1.f : 0.f;
+      // Four steps per trip: the operands of a step are requested two steps ahead, so that their LDS latency is
+      // covered by two chain steps (a single wave has nobody else to hide it); H is even, a last pair is handled alone.
+      float ca[12], cb[12], cc[12], cd[12], va, vb, vc, vd;
       float p = 0.f;
-      float col[12], btv;
+      auto load_col = [&](int k, float (&cf)[12], float& btv) {       // k-th step of the backward pass: i = H - 1 - k
+        const int i = H - 1 - (k < H ? k : H - 1);
 #pragma unroll
-      for (int m = 0; m < 12; ++m) col[m] = sm.Mf[H - 1][m][rn];
-      btv = sm.u.itv.bt[H - 1][r6];
+        for (int m = 0; m < 12; ++m) cf[m] = sm.Mf[i][m][rn];
+        btv = sm.u.itv.bt[i][r6];
+      };
+      auto back_step = [&](int k, const float (&cf)[12], float btv) {
+        const int i = H - 1 - k;
+        const float uu = fmaf(-sel, btv, p);      // [p1; g = p2 - bt]
+        sm.u.itv.gs[i][d6] = uu;
+        p = row_matvec12(p, uu, cf);
+      };
+      load_col(0, ca, va);
+      load_col(1, cb, vb);
+      int k = 0;
 #pragma unroll 1
-      for (int i = H - 1; i >= 0; --i) {
-        // the operands of the next step are requested before this step's chain starts
-        const int ip = i > 0 ? i - 1 : 0;
-        float coln[12];
-#pragma unroll
-        for (int m = 0; m < 12; ++m) coln[m] = sm.Mf[ip][m][rn];
-        const float btn = sm.u.itv.bt[ip][r6];
+      for (; k + 4 <= H; k += 4) {
+        load_col(k + 2, cc, vc);
+        load_col(k + 3, cd, vd);
         BMPC_SCHED_BARRIER();
-        const float uu = rn >= 6 ? p - btv : p;
-        if (rn >= 6) sm.u.itv.gs[i][r6] = uu;     // g_i (same value from the four rows and the clone lanes)
-        float a0 = p, a1 = 0.f, a2 = 0.f;
-        a0 = fmaf(col[0], row_bcast<0>(uu), a0);  a1 = fmaf(col[1], row_bcast<1>(uu), a1);  a2 = fmaf(col[2], row_bcast<2>(uu), a2);
-        a0 = fmaf(col[3], row_bcast<3>(uu), a0);  a1 = fmaf(col[4], row_bcast<4>(uu), a1);  a2 = fmaf(col[5], row_bcast<5>(uu), a2);
-        a0 = fmaf(col[6], row_bcast<6>(uu), a0);  a1 = fmaf(col[7], row_bcast<7>(uu), a1);  a2 = fmaf(col[8], row_bcast<8>(uu), a2);
-        a0 = fmaf(col[9], row_bcast<9>(uu), a0);  a1 = fmaf(col[10], row_bcast<10>(uu), a1); a2 = fmaf(col[11], row_bcast<11>(uu), a2);
-        p = a0 + (a1 + a2);
-#pragma unroll
-        for (int m = 0; m < 12; ++m) col[m] = coln[m];
-        btv = btn;
+        back_step(k, ca, va);
+        back_step(k + 1, cb, vb);
+        load_col(k + 4, ca, va);
+        load_col(k + 5, cb, vb);
+        BMPC_SCHED_BARRIER();
+        back_step(k + 2, cc, vc);
+        back_step(k + 3, cd, vd);
       }
+      if (k < H) { back_step(k, ca, va); back_step(k + 1, cb, vb); }
       BMPC_WAVE_SYNC();
-      // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value)
+      // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value); it replaces bt
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
         const int j = js[s];
         float acc = 0.f;
 #pragma unroll
         for (int m = 0; m < 6; ++m) acc = fmaf(sm.Sinv[j][c][m], sm.u.itv.gs[j][m], acc);
-        sm.u.itv.wv[j][c] = acc;
+        sm.u.itv.bt[j][c] = acc;
       }
       BMPC_WAVE_SYNC();
       float x = 0.f;
-      float rowm[12], wvv;
-#pragma unroll
-      for (int m = 0; m < 12; m += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(&sm.Mf[0][rn][m]);
-        rowm[m] = v.x; rowm[m + 1] = v.y; rowm[m + 2] = v.z; rowm[m + 3] = v.w;
-      }
-      wvv = sm.u.itv.wv[0][r6];
-#pragma unroll 1
-      for (int i = 0; i < H; ++i) {
-        const int ip = i + 1 < H ? i + 1 : i;
-        float rown[12];
+      auto load_row = [&](int k, float (&cf)[12], float& wvv) {
+        const int i = k < H ? k : H - 1;
 #pragma unroll
         for (int m = 0; m < 12; m += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(&sm.Mf[ip][rn][m]);
-          rown[m] = v.x; rown[m + 1] = v.y; rown[m + 2] = v.z; rown[m + 3] = v.w;
+          const float4 v = *reinterpret_cast<const float4*>(&sm.Mf[i][rn][m]);
+          cf[m] = v.x; cf[m + 1] = v.y; cf[m + 2] = v.z; cf[m + 3] = v.w;
         }
-        const float wvn = sm.u.itv.wv[ip][r6];
-        BMPC_SCHED_BARRIER();
-        float a0 = rn >= 6 ? -wvv : 0.f, a1 = 0.f, a2 = 0.f;
-        a0 = fmaf(rowm[0], row_bcast<0>(x), a0);  a1 = fmaf(rowm[1], row_bcast<1>(x), a1);  a2 = fmaf(rowm[2], row_bcast<2>(x), a2);
-        a0 = fmaf(rowm[3], row_bcast<3>(x), a0);  a1 = fmaf(rowm[4], row_bcast<4>(x), a1);  a2 = fmaf(rowm[5], row_bcast<5>(x), a2);
-        a0 = fmaf(rowm[6], row_bcast<6>(x), a0);  a1 = fmaf(rowm[7], row_bcast<7>(x), a1);  a2 = fmaf(rowm[8], row_bcast<8>(x), a2);
-        a0 = fmaf(rowm[9], row_bcast<9>(x), a0);  a1 = fmaf(rowm[10], row_bcast<10>(x), a1); a2 = fmaf(rowm[11], row_bcast<11>(x), a2);
-        const float inc = a0 + (a1 + a2);       // rows 0..5: (C xi2)[rn];  rows 6..11: the acceleration a_i[rn - 6]
-        if (rn >= 6) sm.u.itv.av[i][r6] = inc;
+        wvv = sm.u.itv.bt[i][r6];
+      };
+      auto fwd_step = [&](int i, const float (&cf)[12], float wvv) {
+        // rows 0..5: (C xi2)[rn];  rows 6..11: the acceleration a_i[rn - 6] = -K xi - w
+        const float inc = row_matvec12(-sel * wvv, x, cf);
+        sm.u.itv.av[i][d6] = inc;
         x += inc;
         sm.u.itv.xi[i][rn] = x;
-#pragma unroll
-        for (int m = 0; m < 12; ++m) rowm[m] = rown[m];
-        wvv = wvn;
+      };
+      load_row(0, ca, va);
+      load_row(1, cb, vb);
+      k = 0;
+#pragma unroll 1
+      for (; k + 4 <= H; k += 4) {
+        load_row(k + 2, cc, vc);
+        load_row(k + 3, cd, vd);
+        BMPC_SCHED_BARRIER();
+        fwd_step(k, ca, va);
+        fwd_step(k + 1, cb, vb);
+        load_row(k + 4, ca, va);
+        load_row(k + 5, cb, vb);
+        BMPC_SCHED_BARRIER();
+        fwd_step(k + 2, cc, vc);
+        fwd_step(k + 3, cd, vd);
       }
+      if (k < H) { fwd_step(k, ca, va); fwd_step(k + 1, cb, vb); }
     }
     BMPC_WAVE_SYNC();
     BMPC_SSTAMP(3)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
     const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // wave-uniform
+    float dstep[NP];                          // d_f[c] = (null-space part) + L~ a
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       const int j = js[s];
-      float gm[6];
-      f2 lg[6];
+      float gm[6], lg[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         gm[i] = sm.u.itv.av[j][i];
-        lg[i] = *reinterpret_cast<const f2*>(&sm.LG[f].d[j][c][i][0]);
+        lg[i] = sm.LG[f].d[j][c][i];
+      }
+      BMPC_SCHED_BARRIER();
+      float d = ddk[s];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d = fmaf(lg[i], gm[i], d);
+      dstep[s] = d;
+      sm.u.itv.r32[j][f][c] = d;                // (the residual is consumed: its slots carry the step to the foot's lanes)
+      BMPC_PASS_FENCE(s);
+    }
+    BMPC_WAVE_SYNC();
+    float gub[6];                             // row c of the mu-free general rows
+#pragma unroll
+    for (int b = 0; b < 6; ++b) gub[b] = (float)sm.Gu[c][b];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const int j = js[s];
+      float db[6];
+#pragma unroll
+      for (int i = 0; i < 6; i += 2) {
+        const float2 v = *reinterpret_cast<const float2*>(&sm.u.itv.r32[j][f][i]);
+        db[i] = v.x; db[i + 1] = v.y;
       }
       const float xin = sm.u.itv.xi[j][n];
+      const float mus = c < 4 ? sm.muf[j][f] : 0.f;
       BMPC_SCHED_BARRIER();
-      f2 dd = ddk[s];                           // {d_f[c], (G_f d_f)[c]}
+      f2 dd;                                    // {d_f[c], (G_f d_f)[c]}
+      dd.x = dstep[s];
+      {
+        float sg = -mus * db[2];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dd = __builtin_elementwise_fma(lg[i], f2{gm[i], gm[i]}, dd);
+        for (int i = 0; i < 6; ++i) sg = fmaf(gub[i], db[i], sg);
+        dd.y = sg;
+      }
       const RT xto = xo[s] - (RT)dd.x;
       const RT ztg = axg[s] - (RT)dd.y;
       const RT ztb = xto;
@@ -1071,6 +1160,7 @@ stage_body(const DevParams& P, const int B,
       // W x~ = W x - gamma exactly, so the tracking error follows the state response of the solve (f32 increment: it
       // vanishes with the step; rebuilt exactly in f64 every REFRESH_ITERS iterations and before leaving)
       err[s] -= alpha * (RT)xin;
+      BMPC_PASS_FENCE(s);
     }
     ++it;
     BMPC_SSTAMP(4)
@@ -1138,7 +1228,7 @@ stage_body(const DevParams& P, const int B,
   }
 
   // ------------------------------------------------------------------ F. outputs (REF:300-304)
-  // every way out of the loop rebuilt err exactly at its last stopping test: X = x_ref + err = s0 + (err - e0)
+  // every way out of the loop rebuilt err exactly at its last stopping test: X = x_ref + err
 #pragma unroll
   for (int s = 0; s < NP; ++s) {
     if (!(sreal[s] && lane_real)) continue;
@@ -1148,7 +1238,8 @@ stage_body(const DevParams& P, const int B,
     uo[pos] = (float)xo[s];
     if (states) {
       float* so = states + ((size_t)inst * H + j) * 13;
-      so[n] = (float)(sm.s0[j][n] + (err[s] - e0[s]));
+      const RT xrn = (j == 0) ? xfb_n : ((n < 6 && xc_n6 != (RT)0) ? xfb_n + xc_n6 * ((RT)j * dt) : xc_n);      // x_ref[n, j]
+      so[n] = (float)(xrn + err[s]);
       if (n == 0) so[12] = 1.0f;
     }
   }
@@ -1165,6 +1256,7 @@ stage_body(const DevParams& P, const int B,
     if (resid_out) { resid_out[2 * inst] = res_p; resid_out[2 * inst + 1] = res_s; }
   }
 #undef BMPC_SSTAMP
+#undef BMPC_PASS_FENCE
 }
 
 #define BMPC_STAGE_ARGS                                                                                            \
@@ -1174,7 +1266,7 @@ stage_body(const DevParams& P, const int B,
       int32_t* __restrict__ iters_out, float* __restrict__ resid_out, int32_t* __restrict__ status_out,            \
       int32_t* __restrict__ nfactor_out, const DebugOut dbg, const WarmArgs warm
 // waves per SIMD the register allocation aims at: what the LDS image of an instance leaves room for
-template <int NP> struct StageOcc { static constexpr int WPE = NP <= 2 ? 3 : (NP <= 4 ? 2 : 1); };
+template <int NP> struct StageOcc { static constexpr int WPE = 1; };
 template <int NP>
 __global__ void __launch_bounds__(64, StageOcc<NP>::WPE) stage_kernel(BMPC_STAGE_ARGS) {
   stage_body<NP, false>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,

@@ -39,6 +39,29 @@ def test_kernel_source_on_cpu_matches_fixtures(name, idx):
         assert np.abs(o["foot_ref"].transpose(0, 2, 1) - d["foot_ref"][idx]).max() < 1e-6
 
 
+@pytest.mark.parametrize("name,key,idx", [("cfg4_walking_h10", None, [3]), ("edge_cases_h10", None, [2]), ("cfg_hgen", 14, [0])])
+def test_stage_kernel_source_on_cpu_matches_fixtures(name, key, idx):
+    """The stage-structured kernel (bmpc_stage.hip: Riccati recursion, scans over the steps, phantom steps past the
+    horizon at h = 14, the DPP row broadcasts of the two passes emulated lane by lane) on the CPU against the fixtures."""
+    import __graft_entry__ as ge
+    ge.build()
+    import biped_mpc_py_amd as bm
+    d0 = util.load(name)
+    d = d0 if key is None else {k[len("h%d_" % key):]: d0[k] for k in d0.files if k.startswith("h%d_" % key)}
+    h = 10 if key is None else key
+    half = 5 if key is None else int(d["half"][0])
+    mpc = bm.MPC()
+    mpc.h = h
+    cp = bm.pack_params(mpc, bm.Biped(), half=half, solver_options=dict(path=2))
+    mu = d["mu_steps"][idx] if "mu_steps" in d and d["mu_steps"].size else None
+    o = emu.solve(cp, d["x_fb"][idx], d["foot"][idx], d["contact"][idx], util.phases(d["t"][idx], mpc.dt, h),
+                  x_cmd=d["x_cmd"][idx], mu=mu)
+    assert (o["status"] == 0).all()
+    assert util.rel_err(o["controls"].astype(float), d["controls"][idx]).max() <= util.REL_TOL
+    assert util.rel_err(o["states"].astype(float), d["states"][idx]).max() <= util.REL_TOL
+    assert o["iters"].max() <= 150
+
+
 def test_warm_start_same_optimum_on_cpu():
     """Warm start (kernel source on the CPU): a second solve that starts from the state the first one left --
     after the state feedback of one control period -- reaches the oracle's optimum of the NEW problem (the saving

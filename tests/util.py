@@ -35,3 +35,17 @@ def phases(t, dt, h):
 
 
 from biped_mpc_py_amd.synth import synth_batch  # noqa: E402,F401  (SURVEY 8(d) generator, shared with bench.py)
+
+
+def wrench_map(r):
+    """W (6h x 12h) with b_j = W_j u_j = [tau_j; F_j], u_j = [f1 f2 m1 m2] (REF:174-180); r (h, 2, 3) lever arms."""
+    from oracle import bmpc_oracle as orc
+    h = r.shape[0]
+    W = np.zeros((6 * h, 12 * h))
+    for j in range(h):
+        Wj = np.zeros((6, 12))
+        Wj[0:3, 0:3], Wj[0:3, 3:6] = orc.skew(r[j, 0]), orc.skew(r[j, 1])
+        Wj[0:3, 6:9] = Wj[0:3, 9:12] = np.eye(3)
+        Wj[3:6, 0:3] = Wj[3:6, 3:6] = np.eye(3)
+        W[6 * j:6 * j + 6, 12 * j:12 * j + 12] = Wj
+    return W
