@@ -121,10 +121,23 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   } else if (p.penalty_mode != BMPC_PENALTY_ABSOLUTE) {
     return fail(BMPC_ERR_INVALID, "unknown penalty_mode %d", p.penalty_mode);
   }
-  d->rho = (float)(p.rho * std::sqrt(pr * pf));          // between the soft and the stiff end
-  d->rho_eq = (float)(p.rho * p.rho_eq_scale * pf);
-  d->rho_lo = (float)(p.rho_lo * pr);
-  d->rho_hi_f = (float)(p.rho_hi_f * pf); d->rho_hi_m = (float)(p.rho_hi_m * pm);
+  double rho0 = p.rho * std::sqrt(pr * pf);              // between the soft and the stiff end
+  double rho_eq = p.rho * p.rho_eq_scale * pf, rho_lo = p.rho_lo * pr, hi_f = p.rho_hi_f * pf, hi_m = p.rho_hi_m * pm;
+  if (p.penalty_mode == BMPC_PENALTY_SCALED) {
+    // What f32 holds: the stored null-space factor Ka^-1 has entries up to 1 / (2R + rho_lo) with 6e-8 relative error,
+    // and that error is multiplied by the stiffest penalty of the block when the step is taken: above
+    // eps_f32 x rho_max / (2R + rho_lo) ~ 1 the iteration stops contracting (seen as active-set cycling at R / 100).
+    // The ceilings stay six decades above the soft end (error factor 0.06).
+    double rmin = p.R[0];
+    for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p.R[i]);
+    const double top = 1e6 * (2 * rmin + rho_lo);
+    rho_eq = std::fmin(rho_eq, top); hi_f = std::fmin(hi_f, top); hi_m = std::fmin(hi_m, top);
+    rho0 = std::fmin(rho0, hi_f);
+  }
+  d->rho = (float)rho0;
+  d->rho_eq = (float)rho_eq;
+  d->rho_lo = (float)rho_lo;
+  d->rho_hi_f = (float)hi_f; d->rho_hi_m = (float)hi_m;
   d->eps_pri = (float)p.eps_pri; d->eps_dua = (float)p.eps_dua; d->kappa = (float)p.kappa;
   return BMPC_OK;
 }
