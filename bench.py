@@ -7,6 +7,7 @@ BASELINE.json configs[1] (B = 4096 per GPU, horizon 10, double support).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]            the driver's contract
     python bench.py --config {2,3,4,5}                              another BASELINE config (own roofline line)
+    python bench.py --config {6,7}                                  the long-horizon extensions h = 32 / 40 (stage-structured kernels)
     python bench.py --gpus 8 --config 4 --scaling strong            ONE 65536 batch sharded N ways
 
 --gpus N > 1 works with or without a launcher: under torch.distributed.run (RANK / WORLD_SIZE in the
@@ -56,12 +57,18 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json config number (1-based)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5, 6, 7),
+                    help="BASELINE.json config number (1-based); 6 / 7: the long-horizon extensions h = 32 / 40")
+    ap.add_argument("--path", choices=("auto", "dense", "stage", "best"), default=None,
+                    help="kernel family: dense inverse, stage-structured, the library's choice, or `best` = time both "
+                         "before the timed region and take the faster (default for config 5: its h = 20 has both)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=None, help="weak: instances per GPU per step (default 4096)")
     ap.add_argument("--total", type=int, default=None, help="strong: instances in the one global batch (default 65536)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the results on their ranks")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="instances for the all-core CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="instances for the all-core CPU baseline and the in-run parity (0 = skip; default: the whole batch "
+                         "at h = 10, i.e. ~4 s on 16 cores, 256 otherwise)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal only: initialise torch.distributed and run the collectives even with one rank")
@@ -91,7 +98,12 @@ def self_launch(n, argv):
     rc = 0
     pending = set(range(n))
     out0 = b""
+    deadline = time.monotonic() + float(os.environ.get("BMPC_BENCH_LAUNCH_TIMEOUT", "1500"))
     while pending:
+        if time.monotonic() > deadline:               # a rank stuck in a rendezvous must not outlive the launcher
+            for q in pending:
+                procs[q].kill()
+            rc = rc or 124
         for r in sorted(pending):
             if r == 0:
                 try:
@@ -132,6 +144,18 @@ def flops_run(h, iters, nfactor):
     f_setup = 2.0 * (27 * h * (h - 1) / 2 + 9 * h * h * (h + 1) / 2 + 40 * h * h)
     f_factor = 1.0 * n ** 3 + 2.0 * 3500 * h
     f_iter = 2.0 * h * (690 + 48 * h)
+    return f_setup + nfactor * f_factor + iters * f_iter, dict(setup=f_setup, factor=f_factor, iteration=f_iter)
+
+
+def flops_run_stage(h, iters, nfactor):
+    """Flops of the stage-structured path (bmpc_stage.hip; 1 MAC = 2 flops): O(h) everywhere.  Set-up: references, step
+    data, free response (~400 per step).  Per factorisation: the 6x6 block algebra (as the dense path, 7000 per step)
+    and the backward Riccati recursion -- per step one 6x6 LDL' with 24 right-hand sides and the Schur complement /
+    congruence products on 6x6 blocks (~2 x 2100 MACs).  Per iteration: constraint products and residual (690 per step, as
+    the dense path), the adjoint of the tracking error (~60), two 12x12 mat-vecs of the stage solve and S^-1 g (2 x 324)."""
+    f_setup = 2.0 * 400 * h
+    f_factor = 2.0 * (3500 + 2100) * h
+    f_iter = 2.0 * h * (690 + 60 + 324)
     return f_setup + nfactor * f_factor + iters * f_iter, dict(setup=f_setup, factor=f_factor, iteration=f_iter)
 
 
@@ -304,7 +328,9 @@ def run_rank(args):
     B = hi - lo
     use_x_cmd = bool(cfg["kw"].get("vx_cmd"))
     s["use_x_cmd"] = use_x_cmd
-    cp = bm.pack_params(mpc, bm.Biped(), half=s["half"])
+    path_arg = args.path or ("best" if args.config == 5 else "auto")
+    cp = bm.pack_params(mpc, bm.Biped(), half=s["half"],
+                        solver_options=dict(path={"auto": 0, "dense": 1, "stage": 2, "best": 0}[path_arg]))
     if use_dist:                                    # C0: one parameter block for every rank
         sharding.broadcast_params(cp, src=0, device=coll_dev)
     solver = bm.BatchSolver(cparams=cp, device=dev_index, max_batch=max(B, total if (strong and rank == 0) else B))
@@ -339,7 +365,31 @@ def run_rank(args):
         if strong:
             pbuf = torch.from_numpy(np.frombuffer(bytes(cp), dtype=np.uint8).copy()).to(coll_dev)
 
+    # `best`: both kernel families (where both exist) on this batch before the timed region; rank 0's choice is
+    # everybody's.  The families share the outer method, so the answer is the same either way.
+    path_trial = None
+    if path_arg == "best" and solver._lib.bmpc_supported_horizon_path(h, 1) and solver._lib.bmpc_supported_horizon_path(h, 2):
+        path_trial = {}
+        for name, code in (("dense", 1), ("stage", 2)):
+            cpt = bm.pack_params(mpc, bm.Biped(), half=s["half"], solver_options=dict(path=code))
+            solver.set_params(cpt)
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                solver.solve_device(tin["x_fb"], tin["foot"], tin["contact"], tin["phase"], x_cmd=tin["x_cmd"], mu=tin["mu"],
+                                    controls=o_u2[0], iters=o_it, status=o_st, nfactor=o_nf)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                path_trial[name] = e0.elapsed_time(e1) if rep else 1e30          # (first launch: code load)
+        pick = torch.tensor([1 if path_trial["dense"] <= path_trial["stage"] else 2], dtype=torch.int32, device=coll_dev)
+        if use_dist:
+            dist.broadcast(pick, src=0)
+        cp = bm.pack_params(mpc, bm.Biped(), half=s["half"], solver_options=dict(path=int(pick.item())))
+        solver.set_params(cp)
+    path_used = {1: "dense", 2: "stage"}[int(solver._lib.bmpc_solver_path(solver._h))]
+
     kev = []
+    gev = []                                        # host time spent waiting for a step's gather (N > 1)
     nstep = [0]
 
     def drain():
@@ -357,8 +407,11 @@ def run_rank(args):
         b = nstep[0] & 1
         nstep[0] += 1
         if gather and pending[b] is not None:
+            tw = time.perf_counter()
             pending[b].wait()                       # (NCCL: the current stream waits, not the host)
             pending[b] = None
+            if timed:
+                gev.append(1e3 * (time.perf_counter() - tw))
         if gather and strong:                       # C0 inside the step: the block every rank solves with
             dist.broadcast(pbuf, src=0)
         o_u = o_u2[b]
@@ -402,7 +455,12 @@ def run_rank(args):
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))     # average launch duration, timed region
     if rank == 0:
         _log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms per step, kernel {kernel_ms:.3f} ms")
+    kernel_ms_ranks = [kernel_ms]
     if use_dist:
+        own = torch.tensor([kernel_ms], dtype=torch.float64, device=coll_dev)
+        allk = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(allk, own)
+        kernel_ms_ranks = [float(v.item()) for v in allk]
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
@@ -412,16 +470,25 @@ def run_rank(args):
     status = o_st.cpu().numpy()
     line = None
     if rank == 0:
+        from biped_mpc_py_amd.synth import kernel_source_hash
         fl_s = flops_survey(h, float(iters.mean()))
-        fl_r, parts = flops_run(h, float(iters.mean()), float(nfac.mean()))
-        ach = fl_s * B / (kernel_ms * 1e-3) / 1e12
-        ach_min = fl_r * B / (kernel_ms * 1e-3) / 1e12
-        traffic, traffic_source = None, None          # HBM bytes per launch: PMC passes need rocprofv3 (profiles/)
+        fl_r, parts = (flops_run if path_used == "dense" else flops_run_stage)(h, float(iters.mean()), float(nfac.mean()))
+        ach_s = fl_s * B / (kernel_ms * 1e-3) / 1e12
+        ach = fl_r * B / (kernel_ms * 1e-3) / 1e12
+        # HBM bytes per launch and the MFMA share need rocprofv3 --pmc passes (tools/profile_round.sh -> profiles/); what
+        # is replayed here was measured with THESE kernel sources and this path, or it is refused
+        traffic, traffic_source, mfma_ops = None, None, None
+        ksha = kernel_source_hash()
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
                 for pm in json.load(fh):
-                    if pm.get("batch") == B and pm.get("config") == args.config:
+                    if pm.get("batch") == B and pm.get("config") == args.config and pm.get("path", "dense") == path_used:
+                        if pm.get("kernel_sha") != ksha:
+                            traffic_source = (f"profiles/pmc_summary.json holds a figure for other kernel sources "
+                                              f"({pm.get('kernel_sha')} != {ksha}): refused; rerun tools/profile_round.sh")
+                            continue
                         traffic = pm["traffic_bytes_per_launch"]
+                        mfma_ops = pm.get("sq_per_launch", {}).get("SQ_INSTS_VALU_MFMA_MOPS_F32")
                         traffic_source = "replayed from " + pm.get("source", "profiles/pmc_summary.json") + \
                                          " (rocprofv3 --pmc passes of this command; not measured in this run)"
         except (OSError, ValueError, KeyError, TypeError):
@@ -437,6 +504,10 @@ def run_rank(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg['label']}; {what}, inputs resident in HBM",
                        "baseline_config": args.config, "batch_per_gpu": B, "total": total, "horizon": h,
+                       "path": path_used, "path_choice": (
+                           {"how": "both kernel families timed on this batch before the timed region (ms per launch)", **path_trial}
+                           if path_trial else {"how": f"--path {path_arg}"}),
+                       "scaling": args.scaling,
                        "residual_dtype": "f64", "collectives_in_step": (["broadcast(params)"] if gather and strong else []) +
                        (["all_gather(controls)"] if gather else []),
                        "mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
@@ -444,15 +515,30 @@ def run_rank(args):
                        "not_converged": int((status != 0).sum())},
             "roofline": {"bound": "valu_f32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_TFLOPS,
-                         "achieved_minimal": ach_min, "frac_minimal": ach_min / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": f"bmpc::solve_kernel<{h}>", "kernel_ms": kernel_ms,
-                         "flops_per_solve": fl_s, "flops_per_solve_minimal": fl_r, "flops_parts_minimal": parts,
-                         "note": "compute-bound on the packed-f32 vector pipe (no MFMA in this kernel: the f32 matrix "
-                                 "rate of CDNA4 equals the vector rate); `achieved` uses SURVEY 8(d)'s dense "
-                                 "condensed-ADMM flop formula, `achieved_minimal` the flops of the algorithm that runs",
+                         "achieved_survey_formula": ach_s, "frac_survey_formula": ach_s / PEAK_FP32_TFLOPS,
+                         "mfma_util": 0.0, "mfma_ops_counter": mfma_ops,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel_sha": ksha,
+                         "kernel": (f"bmpc::solve_kernel<{h}>" if path_used == "dense" else f"bmpc::stage_kernel<{(h + 4) // 5}>"),
+                         "kernel_ms": kernel_ms,
+                         "flops_per_solve": fl_r, "flops_parts": parts, "flops_per_solve_survey_formula": fl_s,
+                         "note": "`achieved` / `frac`: the flops of the algorithm that runs (symmetric work counted once) over "
+                                 "the average launch duration, against the f32 vector peak (= the f32 matrix peak on CDNA4); "
+                                 "`*_survey_formula`: SURVEY 8(d)'s dense condensed-ADMM flop count for the same solves, kept "
+                                 "for comparison with earlier rounds.  mfma_util is 0 by construction: no MFMA instruction in "
+                                 "either kernel family (SQ_INSTS_VALU_MFMA_MOPS_F32 = 0 in profiles/); the wrench-space form "
+                                 "removes the Hessian GEMM, two matrix-core sweeps were built and measured slower (DESIGN 9). "
+                                 "The path is latency-bound: chains of dependent LDS exchanges, not a pipe",
                          "hbm_algorithmic_bytes_per_solve": hbm_bytes_per_solve(h, use_x_cmd, s["mu"] is not None)},
         }
+        if world > 1:
+            line["ranks"] = {"kernel_ms_min": min(kernel_ms_ranks), "kernel_ms_max": max(kernel_ms_ranks),
+                             "kernel_ms_per_rank": kernel_ms_ranks,
+                             "gather_wait_ms_per_step_rank0": (float(np.mean(gev)) if gev else None),
+                             "note": ("weak scaling shards nothing: every rank solves its own batch and value grows with N by "
+                                      "construction unless the all_gather of the controls (2 MB per rank and step) hurts; the "
+                                      "north_star partitioning of ONE 65536 batch is `--config 4 --scaling strong` (or --config 5)"
+                                      if not strong else
+                                      "ONE global batch sharded contiguously; per step broadcast(params) + solve + all_gather")}
     # strong scaling: the gathered controls against the single-GPU solve of the whole batch, bit for bit
     if gather and strong:
         fence()
@@ -481,8 +567,9 @@ def run_rank(args):
             solver.solve(*xs, **kw)
         line["value_incl_pcie"] = {"value": B * reps / (time.perf_counter() - t0), "unit": "solves/s", "n_gpus": 1,
                                    "what": "bmpc_solve_batch on host arrays: H2D + kernel + D2H + fp64 conversion, one GPU"}
-        if world == 1 and args.cpu_sample > 0:
-            n = min(args.cpu_sample, B)
+        cpu_sample = args.cpu_sample if args.cpu_sample is not None else (B if h == 10 else 256)
+        if world == 1 and cpu_sample > 0:
+            n = min(cpu_sample, B)
             got = o_u.cpu().numpy().astype(np.float64)
             try:
                 ref_full, ref_plain, cb = cpu_baseline(s, h, mpc.dt, n)

@@ -6,13 +6,13 @@ does not load the shared library; the first solver call does, and raises if it i
 """
 from .params import MPC, Biped, pack_params                                  # noqa: F401
 from .api import (BatchSolver, solve_mpc, solve_mpc_batch, get_contact_sequence,   # noqa: F401
-                  phase_index, lowLevelControl, getFootPositionWorld, SolverStatusWarning,
+                  phase_index, phase_indices, lowLevelControl, getFootPositionWorld, SolverStatusWarning,
                   close_cached_solvers, get_reference_trajectory, get_reference_foot_trajectory,
                   reference_trajectories_batch)
 from . import sharding                                                        # noqa: F401
 from ._lib import BmpcError                                                   # noqa: F401
 
 __all__ = ["MPC", "Biped", "pack_params", "BatchSolver", "solve_mpc", "solve_mpc_batch",
-           "get_contact_sequence", "phase_index", "lowLevelControl", "getFootPositionWorld", "sharding",
+           "get_contact_sequence", "phase_index", "phase_indices", "lowLevelControl", "getFootPositionWorld", "sharding",
            "BmpcError", "SolverStatusWarning", "close_cached_solvers",
            "get_reference_trajectory", "get_reference_foot_trajectory", "reference_trajectories_batch"]

@@ -26,6 +26,33 @@ def phase_index(t, mpc_or_dt, h=None):
     return int(t // dt) % int(h)
 
 
+def phase_indices(t, dt, h):
+    """`phase_index` for an array of times: np.floor_divide on float64 has CPython's `//` semantics (the quotient is
+    corrected by the fmod remainder, REF:56-57 / 99-100 rely on exactly that at step boundaries), so this is the
+    same arithmetic without a Python loop (tests/test_host_logic.py holds it to `phase_index` on and next to 3000
+    step boundaries).  t: array of seconds (>= 0) -> int32 array."""
+    tt = np.asarray(t, np.float64).reshape(-1)
+    k = np.floor_divide(tt, np.float64(dt))
+    return (k.astype(np.int64) % int(h)).astype(np.int32)
+
+
+def _contact_u8(contact, B, h):
+    """(B, h, 2) uint8 contact table with entries in {0, 1}.  uint8 / bool input takes one pass (a max), anything
+    else is checked value by value."""
+    c = np.asarray(contact)
+    if c.shape[-1] != 2 or c.size != B * h * 2:
+        raise ValueError(f"contact must have shape (B, {h}, 2)")
+    if c.dtype == np.uint8 or c.dtype == np.bool_:
+        c8 = c.view(np.uint8) if c.dtype == np.bool_ else c
+        if c8.size and c8.max() > 1:
+            raise ValueError("contact entries must be 0 or 1")
+    else:
+        c8 = c.astype(np.uint8)
+        if not np.array_equal(c8, c):
+            raise ValueError("contact entries must be 0 or 1")
+    return np.ascontiguousarray(c8.reshape(B, h, 2))
+
+
 def get_contact_sequence(t, mpc, half=None):
     """REF:50-59.  Default: the reference's 20x2 table of 5-on/5-off, rows k..k+9 (ten rows whatever
     `mpc.h` is -- reference quirk).  With `half` given: the same schedule with that half period, continued
@@ -78,12 +105,7 @@ class BatchSolver:
         x_fb = np.ascontiguousarray(np.asarray(x_fb, np.float32).reshape(-1, 12))
         B = x_fb.shape[0]
         foot = np.ascontiguousarray(np.asarray(foot, np.float32).reshape(B, 6))
-        contact = np.asarray(contact)
-        if contact.shape[-1] != 2 or contact.size != B * h * 2:
-            raise ValueError(f"contact must have shape (B, {h}, 2)")
-        if not np.isin(contact, (0, 1)).all():
-            raise ValueError("contact entries must be 0 or 1")
-        contact = np.ascontiguousarray(contact.reshape(B, h, 2).astype(np.uint8))
+        contact = _contact_u8(contact, B, h)
         phase = np.ascontiguousarray(np.asarray(phase, np.int32).reshape(B))
         if x_cmd is not None:
             x_cmd = np.ascontiguousarray(np.asarray(x_cmd, np.float32).reshape(B, 12))
@@ -172,15 +194,26 @@ class BatchSolver:
         pf_w = np.ascontiguousarray(np.asarray(pf_w, np.float32).reshape(B, 6))
         q = np.ascontiguousarray(np.asarray(q, np.float32).reshape(B, 10))
         qd = np.ascontiguousarray(np.asarray(qd, np.float32).reshape(B, 10))
-        c0 = np.asarray(contact0).reshape(B, 2)
-        if not np.isin(c0, (0, 1)).all():
-            raise ValueError("contact entries must be 0 or 1")
-        c0 = np.ascontiguousarray(c0.astype(np.uint8))
+        c0 = _contact_u8(np.asarray(contact0).reshape(B, 1, 2), B, 1).reshape(B, 2)
         u0 = np.ascontiguousarray(np.asarray(u0, np.float32).reshape(B, 12))
         tau = np.empty((B, 10), np.float32)
         _lib.check(self._lib.bmpc_low_level_control(self._h, B, _ptr(x_fb), _ptr(t), _ptr(pf_w), _ptr(q), _ptr(qd),
                                                     _ptr(c0), _ptr(u0), _ptr(tau)))
         return tau.astype(np.float64)
+
+    def _gait(self, period, offset, duty):
+        """`bmpc_gait` for a schedule that departs from this solver's default (None: the default)."""
+        if period is None and offset is None and duty is None:
+            return None
+        gait = _lib.CGait()
+        _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
+        if period is not None:
+            gait.period = int(period)
+        if offset is not None:
+            gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
+        if duty is not None:
+            gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        return gait
 
     def contact_sequence(self, t, period=None, offset=None, duty=None, want_contact=True):
         """Batched gait scheduler on the device (REF:50-59 and the phase index of REF:99-100).
@@ -188,16 +221,7 @@ class BatchSolver:
         solver's half period; otherwise leg g stands at schedule step n iff ((n + offset[g]) % period) < duty[g]."""
         t = np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1))
         B = t.shape[0]
-        gait = None
-        if period is not None or offset is not None or duty is not None:
-            gait = _lib.CGait()
-            _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
-            if period is not None:
-                gait.period = int(period)
-            if offset is not None:
-                gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
-            if duty is not None:
-                gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        gait = self._gait(period, offset, duty)
         phase = np.empty(B, np.int32)
         contact = np.empty((B, self.h, 2), np.uint8) if want_contact else None
         _lib.check(self._lib.bmpc_contact_sequence(self._h, B, _ptr(t), None if gait is None else C.byref(gait),
@@ -216,16 +240,7 @@ class BatchSolver:
             phase = torch.empty(B, dtype=torch.int32, device=dev)
         if contact is None:
             contact = torch.empty((B, self.h, 2), dtype=torch.uint8, device=dev)
-        gait = None
-        if period is not None or offset is not None or duty is not None:
-            gait = _lib.CGait()
-            _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
-            if period is not None:
-                gait.period = int(period)
-            if offset is not None:
-                gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
-            if duty is not None:
-                gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        gait = self._gait(period, offset, duty)
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         _lib.check(self._lib.bmpc_contact_sequence_device(self._h, B, t.data_ptr(), None if gait is None else C.byref(gait),
                                                           phase.data_ptr(), contact.data_ptr(), st))
@@ -272,16 +287,7 @@ class BatchSolver:
                 raise ValueError(f"expected contiguous {dtype} tensor of shape {shape} on {dev}")
             return tn.data_ptr()
 
-        gait = None
-        if period is not None or offset is not None or duty is not None:
-            gait = _lib.CGait()
-            _lib.check(self._lib.bmpc_gait_default(C.byref(gait), int(self.cparams.half)))
-            if period is not None:
-                gait.period = int(period)
-            if offset is not None:
-                gait.offset[0], gait.offset[1] = int(offset[0]), int(offset[1])
-            if duty is not None:
-                gait.duty[0], gait.duty[1] = int(duty[0]), int(duty[1])
+        gait = self._gait(period, offset, duty)
         u0 = torch.empty((steps, B, 12), dtype=torch.float32, device=dev)
         xt = torch.empty((steps, B, 12), dtype=torch.float32, device=dev)
         its = torch.empty((steps, B), dtype=torch.int32, device=dev) if want_iters else None
@@ -359,8 +365,7 @@ def solve_mpc_batch(x_fb, t, foot, contact, mpc=None, biped=None, x_cmd=None, mu
     mpc = mpc if mpc is not None else MPC()
     solver = _cached_solver(mpc, biped, half, device, solver_options)
     if phase is None:
-        tt = np.asarray(t, float).reshape(-1)
-        phase = np.array([phase_index(v, mpc) for v in tt], np.int32)
+        phase = phase_indices(t, mpc.dt, mpc.h)
     states, controls, info = solver.solve(x_fb, foot, contact, phase, x_cmd=x_cmd, mu=mu)
     if return_info:
         return states, controls, info
@@ -390,7 +395,7 @@ def reference_trajectories_batch(x_fb, t, foot, contact, mpc=None, biped=None, x
     solver = _cached_solver(mpc, biped, half, device, None)
     x_fb = np.asarray(x_fb, float).reshape(-1, 12)
     if phase is None:
-        phase = np.array([phase_index(v, mpc) for v in np.asarray(t, float).reshape(-1)], np.int32)
+        phase = phase_indices(t, mpc.dt, mpc.h)
     x_ref, foot_ref, _, _ = solver.assemble(x_fb, foot, contact, phase, x_cmd=x_cmd)
     B, h = x_ref.shape[0], x_ref.shape[1]
     xr = np.concatenate([x_ref.transpose(0, 2, 1), np.ones((B, 1, h))], axis=1)       # REF:62: 13th row of ones
@@ -409,8 +414,10 @@ def get_reference_foot_trajectory(x_fb, t, foot, mpc, contact, half=None, device
     """Drop-in for REF:72-109: returns foot_ref (6,h) fp64 (`contact` as REF:102 reads it: its first row decides)."""
     h = int(mpc.h)
     contact = np.asarray(contact)
+    # REF:102 reads contact[0, :] only, and REF:58 hands over ten rows whatever mpc.h is: row 0 is repeated h times
+    c = np.broadcast_to(contact.reshape(-1, 2)[0:1], (h, 2))
     _, fr = reference_trajectories_batch(np.asarray(x_fb, float).reshape(1, 12), [float(t)], np.asarray(foot, float).reshape(1, 6),
-                                         contact[None, :h, :], mpc=mpc, half=half, device=device)
+                                         c[None], mpc=mpc, half=half, device=device)
     return fr[0]
 
 

@@ -202,9 +202,9 @@ template <int H>
 int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
              const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-             hipStream_t st) {
+             hipStream_t st, const int32_t* order) {
   constexpr int NT = bmpc::Dims<H>::NT;
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : hd->order};
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order};
   if (hd->warm_on && !dbg.assemble_only) {
     const size_t need = (size_t)B * NT * 6;
     if (need > hd->warm.n) hd->warm_valid = false;          // growing the buffer loses the stored state
@@ -231,8 +231,8 @@ template <int NP>
 int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                  const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
                  int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-                 hipStream_t st) {
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : hd->order};
+                 hipStream_t st, const int32_t* order) {
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order};
   if (hd->warm_on && !dbg.assemble_only) {
     const size_t need = (size_t)B * (5 * NP) * 12 * 6;       // [B][5 NP][12][6] doubles
     if (need > hd->warm.n) hd->warm_valid = false;
@@ -258,20 +258,20 @@ int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, co
 int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
            const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
            int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-           hipStream_t st) {
+           hipStream_t st, const int32_t* order) {
   // the stage-structured family (bmpc_stage.hip) is compiled per number of steps a lane owns, NP = ceil(h / 5)
   const bool dense_views = dbg.assemble_only && (dbg.Gt || dbg.qt);      // Gt, qt only exist on the dense path
   if (hd->path == BMPC_PATH_STAGE && !(dense_views && dense_horizon(hd->dev.h))) {
     if (dense_views) return fail(BMPC_ERR_INVALID, "Gt / qt views exist for h <= 20 only (h=%d never forms them)", hd->dev.h);
     switch ((hd->dev.h + 4) / 5) {
-#define BMPC_CASE(NN) case NN: return launch_stage<NN>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+#define BMPC_CASE(NN) case NN: return launch_stage<NN>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order);
       BMPC_CASE(2) BMPC_CASE(3) BMPC_CASE(4) BMPC_CASE(5) BMPC_CASE(6) BMPC_CASE(7) BMPC_CASE(8)
 #undef BMPC_CASE
       default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
     }
   }
   switch (hd->dev.h) {
-#define BMPC_CASE(HH) case HH: return launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st);
+#define BMPC_CASE(HH) case HH: return launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order);
     BMPC_DENSE_HORIZONS(BMPC_CASE)
 #undef BMPC_CASE
     default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
@@ -421,10 +421,11 @@ int bmpc_get_params(bmpc_handle h, bmpc_params* out) {
   return BMPC_OK;
 }
 
-int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
-                            const int32_t* phase, const float* x_cmd, const float* mu, float* controls,
-                            float* states, int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
-                            void* stream) {
+// one solve launch with the dispatch order given explicitly (roll-outs use their own, the handle's stays untouched)
+static int solve_device_ordered(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                                const int32_t* phase, const float* x_cmd, const float* mu, float* controls,
+                                float* states, int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
+                                void* stream, const int32_t* order) {
   int rc = check_common(h, B, x_fb, foot, contact, phase, controls);
   if (rc != BMPC_OK) return rc;
   if (B == 0) return BMPC_OK;
@@ -432,11 +433,20 @@ int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float
   hipStream_t st = pick_stream(h, stream);
   bmpc::DebugOut dbg = {nullptr, nullptr, nullptr, nullptr, h->prof_dev, 0};
   HIP_TRY(hipEventRecord(h->ev0, st));
-  rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st);
+  rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st, order);
   if (rc != BMPC_OK) return rc;
   HIP_TRY(hipEventRecord(h->ev1, st));
   h->timed = true;
   return BMPC_OK;
+}
+
+int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                            const int32_t* phase, const float* x_cmd, const float* mu, float* controls,
+                            float* states, int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
+                            void* stream) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  return solve_device_ordered(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor,
+                              stream, h->order);
 }
 
 int bmpc_solve_batch(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
@@ -477,6 +487,7 @@ int bmpc_synchronize(bmpc_handle h) {
   if (!h) return fail(BMPC_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->timed) HIP_TRY(hipEventSynchronize(h->ev1));     // the last solve launch, whatever stream it was given
   return BMPC_OK;
 }
 
@@ -505,7 +516,7 @@ int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* fo
   if (mu) HIP_TRY(hipMemcpyAsync(h->mu.p, mu, n * H * 2 * sizeof(float), hipMemcpyHostToDevice, st));
   bmpc::DebugOut dbg = {h->dbg.p + o_xr, h->dbg.p + o_fr, h->dbg.p + o_gt, h->dbg.p + o_qt, nullptr, 1};
   rc = launch(h, B, h->x_fb.p, h->foot.p, h->contact.p, h->phase.p, x_cmd ? h->x_cmd.p : nullptr,
-              mu ? h->mu.p : nullptr, h->controls.p, nullptr, nullptr, nullptr, nullptr, nullptr, dbg, st);
+              mu ? h->mu.p : nullptr, h->controls.p, nullptr, nullptr, nullptr, nullptr, nullptr, dbg, st, nullptr);
   if (rc != BMPC_OK) return rc;
   if (x_ref) HIP_TRY(hipMemcpyAsync(x_ref, h->dbg.p + o_xr, n * H * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
   if (foot_ref) HIP_TRY(hipMemcpyAsync(foot_ref, h->dbg.p + o_fr, n * H * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -683,21 +694,22 @@ int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const floa
   HIP_TRY(h->ro_iters.ensure(n)); HIP_TRY(h->ro_status.ensure(n));
   hipStream_t st = pick_stream(h, stream);
   if (status_any) HIP_TRY(hipMemsetAsync(status_any, 0, n * sizeof(int32_t), st));
-  const int32_t* user_order = h->order;
-  if (h->longest_first && !user_order) HIP_TRY(h->ro_order.ensure(n));
+  const int32_t* order = h->order;                 // this roll-out's dispatch order (the handle's is left alone)
+  const bool own_order = h->longest_first && !order;
+  if (own_order) HIP_TRY(h->ro_order.ensure(n));
   int rc = BMPC_OK;
   for (int s = 0; s < steps && rc == BMPC_OK; ++s) {
     // t -> (phase, contact) -> solve -> x_fb <- states[:, 0], t += dt: three launches on one stream, no host arithmetic
     // (plus, from the second period on, the dispatch order: the instances that iterated longest last period go first)
     rc = bmpc_contact_sequence_device(h, B, t, gait, h->ro_phase.p, h->ro_contact.p, st);
     if (rc != BMPC_OK) break;
-    if (h->longest_first && !user_order && s > 0) {
+    if (own_order && s > 0) {
       hipLaunchKernelGGL(bmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, st, B, h->ro_iters.p, h->ro_order.p);
       if (hipGetLastError() != hipSuccess) { rc = fail(BMPC_ERR_HIP, "dispatch-order launch failed"); break; }
-      h->order = h->ro_order.p;
+      order = h->ro_order.p;
     }
-    rc = bmpc_solve_batch_device(h, B, x_fb, foot, h->ro_contact.p, h->ro_phase.p, x_cmd, mu, h->ro_controls.p,
-                                 h->ro_states.p, h->ro_iters.p, nullptr, h->ro_status.p, nullptr, st);
+    rc = solve_device_ordered(h, B, x_fb, foot, h->ro_contact.p, h->ro_phase.p, x_cmd, mu, h->ro_controls.p,
+                              h->ro_states.p, h->ro_iters.p, nullptr, h->ro_status.p, nullptr, stream, order);
     if (rc != BMPC_OK) break;
     hipLaunchKernelGGL(bmpc::rollout_feedback_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, (int)H, h->params.dt,
                        h->ro_states.p, h->ro_controls.p, h->ro_iters.p, h->ro_status.p, x_fb, t,
@@ -705,7 +717,6 @@ int bmpc_rollout_device(bmpc_handle h, int B, int steps, float* x_fb, const floa
                        iters_traj ? iters_traj + (size_t)s * n : nullptr, status_any);
     if (hipGetLastError() != hipSuccess) rc = fail(BMPC_ERR_HIP, "roll-out launch failed");
   }
-  h->order = user_order;
   return rc;
 }
 

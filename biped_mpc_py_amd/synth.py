@@ -47,4 +47,20 @@ CONFIGS = {
     3: dict(h=16, gait="walking", seed=2, kw=dict(vx_cmd=True), batch=4096, label="configs[2]: horizon 16, alternating single support (half period 8), random v_x command"),
     4: dict(h=10, gait="mixed", seed=3, kw=dict(vx_cmd=True), batch=65536, label="configs[3]: horizon 10, mixed gait schedules (standing or any walking phase)"),
     5: dict(h=20, gait="walking", seed=4, kw=dict(vx_cmd=True, per_step_mu=True), batch=65536, label="configs[4]: horizon 20, walking (half period 10), per-step per-foot friction"),
+    # beyond BASELINE.json: the long horizons of SURVEY 8(f) row 4 (stage-structured kernels), config-5 style inputs
+    6: dict(h=32, gait="walking", seed=5, kw=dict(vx_cmd=True, per_step_mu=True), batch=4096, label="extension: horizon 32, walking (half period 16), per-step per-foot friction"),
+    7: dict(h=40, gait="walking", seed=6, kw=dict(vx_cmd=True, per_step_mu=True), batch=4096, label="extension: horizon 40, walking (half period 20), per-step per-foot friction"),
 }
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources: stamps measurements that are replayed later
+    (profiles/pmc_summary.json -> bench.py roofline.traffic), so that a figure taken with other kernels is refused."""
+    import hashlib
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    hsh = hashlib.sha256()
+    for name in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip"):
+        with open(os.path.join(here, name), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]

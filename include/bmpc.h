@@ -169,7 +169,14 @@ int bmpc_solve_batch_device(bmpc_handle h, int B,
                             int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
                             void* stream);
 
-/* Block until everything queued on the handle's own stream is done. */
+/* Block until everything queued on the handle's own stream is done, and the LAST bmpc_solve_batch_device /
+ * bmpc_rollout_device solve launch of this handle whatever stream it was given (earlier launches on a caller's
+ * stream are the caller's to wait for, with that stream).
+ *
+ * One stream in flight per handle: a handle owns ONE set of per-solve state -- the warm-start buffer (read at the
+ * start of a solve, written at its end), the roll-out scratch, the event pair of bmpc_last_kernel_ms -- and nothing
+ * orders two solves of the same handle that run on DIFFERENT streams.  Use one stream per handle at a time (or one
+ * handle per stream); solves on one stream are ordered like any other work on it. */
 int bmpc_synchronize(bmpc_handle h);
 
 /*
@@ -241,8 +248,10 @@ int bmpc_contact_sequence_device(bmpc_handle h, int B, const double* t, const bm
  *   status_any [B] (OR of the per-period status values): each may be NULL.
  *
  * bmpc_set_dispatch_order: workgroups start in index order and an instance's duration varies (35-105 iterations at
- * h = 10), so the last instances of a batch decide when it ends: the same 4096 instances take 15 % less time when the
- * longest are dispatched first (tools/order_probe.py).  The duration cannot be predicted from the inputs, but in a
+ * h = 10), so the last instances of a batch decide when it ends.  Measured on MI355X (4096 instances): a roll-out
+ * spends 3 % less per period with the longest instances first, a plain batch dispatched in its own longest-first order
+ * 1-9 % less depending on the box (15 % only when the INPUTS are permuted, tools/order_probe.py: the indirection
+ * costs part of it).  The duration cannot be predicted from the inputs, but in a
  * closed loop the previous period's iteration count predicts it: with longest_first_rollouts != 0 (default)
  * bmpc_rollout_device sorts every period's dispatch by the iteration counts of the period before (one small
  * kernel).  order_dev, if non-NULL, is a DEVICE permutation of 0 .. B-1 used by every later solve of this handle

@@ -910,3 +910,33 @@ def test_assembly_is_the_condensed_qp_of_the_oracle(name, h, half, idx):
         eg = np.abs(gc - c["gc"]).max() / max(1.0, np.abs(c["gc"]).max())
         print(name, i, "Hc rel err %.2e gc rel err %.2e" % (eh, eg))
         assert eh <= 2e-6 and eg <= 2e-6          # Gt is formed in f64 from f32 step data (Me table)
+
+
+def test_bench_two_ranks_on_one_device_over_rccl_fails_cleanly():
+    """the N-rank RCCL program cannot run on a one-GPU box (RCCL refuses two ranks on one device),
+    but its failure mode can be held: `bench.py --gpus 2 --backend nccl` started bare with both ranks on cuda:0 must come
+    back with a non-zero exit code in bounded time, print no JSON line, and leave no rank behind holding the GPU."""
+    import os
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.device_count() > 1:
+        pytest.skip("more than one GPU visible: the refusal this test expects needs two ranks on ONE device")
+    env = dict(os.environ, BMPC_BENCH_LAUNCH_TIMEOUT="150", NCCL_DEBUG="WARN")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--share-device",
+                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--batch", "256"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    took = time.time() - t0
+    print("exit code", p.returncode, "after %.0f s" % took)
+    print(p.stderr.decode("utf-8", "replace")[-1500:])
+    assert p.returncode != 0
+    assert not any(ln.startswith("{") for ln in p.stdout.decode("utf-8", "replace").splitlines())
+    import psutil
+    me = os.getpid()
+    left = [q for q in psutil.process_iter(["pid", "cmdline", "ppid"])
+            if q.info["pid"] != me and q.info["cmdline"] and any("bench.py" in a for a in q.info["cmdline"])]
+    assert not left, [(q.info["pid"], q.info["cmdline"]) for q in left]
+    # and the GPU still works for this process
+    assert float(torch.ones(4, device="cuda").sum().item()) == 4.0

@@ -19,6 +19,34 @@ def test_phase_and_contact_sequence_match_reference():
     assert bm.get_contact_sequence(0.0, mpc).shape == (10, 2)            # reference quirk: 10 rows
 
 
+def test_vectorised_phase_is_the_reference_floor_division():
+    """`phase_indices` (np.floor_divide, no Python loop over the batch) against REF:56-57's `int(t // dt) % h` on and
+    next to 3000 step boundaries, for three step lengths: floating floor division at a boundary is part of the spec."""
+    import biped_mpc_py_amd as bm
+    for dt, h in ((0.04, 10), (0.02, 16), (0.05, 40)):
+        k = np.arange(3000)
+        base = k * dt
+        t = np.concatenate([base, np.nextafter(base, np.inf), np.nextafter(base, -np.inf).clip(0), base + 0.5 * dt,
+                            k.astype(float) * 0.04 * 1.0000001])
+        want = np.array([int(float(v) // dt) % h for v in t], np.int32)
+        got = bm.phase_indices(t, dt, h)
+        assert got.dtype == np.int32 and np.array_equal(got, want)
+
+
+def test_contact_table_validation_fast_path():
+    from biped_mpc_py_amd.api import _contact_u8
+    c = np.ones((3, 10, 2), np.uint8)
+    assert _contact_u8(c, 3, 10).dtype == np.uint8
+    assert np.array_equal(_contact_u8(c.astype(bool), 3, 10), c)
+    assert np.array_equal(_contact_u8(c.astype(float), 3, 10), c)
+    assert np.array_equal(_contact_u8(c.astype(np.int64).tolist(), 3, 10), c)
+    for bad in (c * 2, c.astype(float) * 0.5, -c.astype(int)):
+        with pytest.raises(ValueError):
+            _contact_u8(bad, 3, 10)
+    with pytest.raises(ValueError):
+        _contact_u8(np.ones((3, 9, 2), np.uint8), 3, 10)
+
+
 def test_pack_params_maps_reference_objects():
     import __graft_entry__ as ge
     ge.build()

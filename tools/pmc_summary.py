@@ -4,13 +4,15 @@ writes <dir>/pmc_summary.json (what bench.py replays as roofline.traffic) for ev
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 cfgs = sorted(int(os.path.basename(d)[3:]) for d in glob.glob(os.path.join(out, "cfg*")))      # every config ever profiled under this tag
-H = {2: 10, 3: 16, 4: 10, 5: 20}
+H = {2: 10, 3: 16, 4: 10, 5: 20, 6: 32, 7: 40}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from biped_mpc_py_amd.synth import kernel_source_hash
 def counters(d):
     acc = {}
     fs = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for f in fs[-1:]:                            # the newest run only (gpurun_out accumulates every call's files)
         for r in csv.DictReader(open(f)):
-            if "solve_kernel" in r["Kernel_Name"]:
+            if "solve_kernel" in r["Kernel_Name"] or "stage_kernel" in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 summ = []
@@ -22,7 +24,8 @@ for c in cfgs:
         continue
     B = line["config"]["batch_per_gpu"]
     fe, wr = counters(os.path.join(o, "pmc_fetch")), counters(os.path.join(o, "pmc_write"))
-    s = {"config": c, "batch": B, "horizon": H[c], "source": "profiles/%s_cfg%d_pmc_*.csv" % (tag, c)}
+    s = {"config": c, "batch": B, "horizon": H[c], "source": "profiles/%s_cfg%d_pmc_*.csv" % (tag, c),
+         "path": line["config"].get("path", "dense"), "kernel_sha": kernel_source_hash()}
     if "FETCH_SIZE" in fe and "WRITE_SIZE" in wr:
         s["fetch_bytes_per_launch"] = 1024.0 * fe["FETCH_SIZE"][0]
         s["write_bytes_per_launch"] = 1024.0 * wr["WRITE_SIZE"][0]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root:  tools/profile_round.sh r02 [config ...]      (default configs: 2 3 5)
+# Run ON THE GPU BOX from the repo root:  tools/profile_round.sh r03 [config ...]      (default configs: 2 3 5 6 7)
 # Per config C (BASELINE.json config number; 2 = the bench default) it leaves under gpurun_out/prof_<tag>/cfgC/:
 #   bench.json                 the plain bench line (python3 bench.py --config C ...)
 #   trace/ ... kernel_stats    rocprofv3 --kernel-trace --stats of the same command
@@ -10,16 +10,16 @@
 # The program after `--` is python3 itself (the profiler's preloaded library initialises the GPU: no env/bash hop).
 set -o pipefail
 tag=${1:-r02}; shift
-cfgs=${@:-2 3 5}
+cfgs=${@:-2 3 5 6 7}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 repo=$PWD
 for c in $cfgs; do
   o=$out/cfg$c; mkdir -p "$o"
-  extra=""; [ "$c" != 2 ] && extra="--batch 8192"
-  [ "$c" = 3 ] && extra="--batch 4096"
-  python3 bench.py --config $c $extra --steps 20 --warmup 3 --cpu-sample $([ "$c" = 2 ] && echo 256 || echo 0) > "$o/bench.json" 2> "$o/bench.err" || { echo "bench cfg$c failed"; tail -5 "$o/bench.err"; exit 1; }
+  extra=""; [ "$c" = 5 ] && extra="--batch 8192"
+  [ "$c" = 3 ] || [ "$c" = 6 ] || [ "$c" = 7 ] && extra="--batch 4096"
+  python3 bench.py --config $c $extra --steps 20 --warmup 3 $([ "$c" = 2 ] || echo "--cpu-sample 0") > "$o/bench.json" 2> "$o/bench.err" || { echo "bench cfg$c failed"; tail -5 "$o/bench.err"; exit 1; }
   echo "cfg$c bench ok: $(cut -c1-160 $o/bench.json)"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$o/trace" -- python3 "$repo/bench.py" --config $c $extra --steps 20 --warmup 3 --cpu-sample 0 > "$o/bench_under_rocprof.json" 2> "$o/trace.err") || { echo "trace cfg$c failed"; tail -5 "$o/trace.err"; exit 1; }
   echo "cfg$c trace ok"
@@ -33,6 +33,10 @@ for c in $cfgs; do
   if [ "$c" = 2 ]; then
     python3 tools/phase_cycles.py 4096 2> /dev/null | grep -v amdgpu.ids > "$o/phase_cycles.txt"
   fi
+  # in-kernel stamps of whichever family the bench line ran
+  hh=$(python3 -c "import json;print(json.load(open('$o/bench.json'))['config']['horizon'])")
+  pp=$(python3 -c "import json;print({'dense':1,'stage':2}[json.load(open('$o/bench.json'))['config']['path']])")
+  python3 tools/stage_probe.py prof 4096 $hh $pp 2> /dev/null | grep -v amdgpu.ids > "$o/phase_cycles_path.txt"
 done
 python3 tools/pmc_summary.py "$out" "$tag"
 echo "done: $out"
