@@ -48,7 +48,7 @@ def _contact_u8(contact, B, h):
             raise ValueError("contact entries must be 0 or 1")
     else:
         c8 = c.astype(np.uint8)
-        if not np.array_equal(c8, c):
+        if not np.array_equal(c8, c) or (c8.size and c8.max() > 1):
             raise ValueError("contact entries must be 0 or 1")
     return np.ascontiguousarray(c8.reshape(B, h, 2))
 
