@@ -215,10 +215,12 @@ stage_body(const DevParams& P, const int B,
     jg[s] = js[s] < H ? js[s] : H - 1;          // index into the per-step inputs in HBM
   }
 
+  // (every lambda below is forced inline: one that is called from two places -- the scans, the exact rebuild -- is
+  //  otherwise a real function inside a large module, and whatever it captures by reference then lives in scratch)
   // scans over the steps of one value per (lane, step), f64: the lane's NP steps are consecutive, so a scan is a local
   // pass in registers plus one exchange of the 5 group totals.  Steps past the horizon contribute nothing.
   int n_scan = 0;
-  auto group_add = [&](RT run, bool suffix) -> RT {
+  auto group_add = [&](RT run, bool suffix) __attribute__((always_inline)) -> RT {
     RT (*tb)[12] = sm.tot[n_scan & 1];
     ++n_scan;
     tb[q][n] = run;
@@ -418,7 +420,7 @@ stage_body(const DevParams& P, const int B,
     irvb[s] = (RT)1 / (RT)rvb[s]; irvg[s] = (RT)1 / (RT)rvg[s];
   }
 
-  auto factor = [&]() {
+  auto factor = [&]() __attribute__((always_inline)) {
     if constexpr (PROF) t_mark = clock64();
 #pragma unroll
     for (int s = 0; s < NP; ++s) sm.rvg[js[s]][f][c] = rvg[s];
@@ -774,7 +776,7 @@ stage_body(const DevParams& P, const int B,
   const RT idt_r = (RT)1 / dt, dtm = dt / (RT)P.m;
 
   // exact axg and err from x (f64): err = e0 + Gam_t W x by two prefix sums over the steps
-  auto refresh = [&]() {
+  auto refresh = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < NP; ++s) sm.u.itv.wg[js[s]][f][c] = xo[s];
     BMPC_WAVE_SYNC();
@@ -1168,7 +1170,7 @@ stage_body(const DevParams& P, const int B,
     const bool adapt_now = (it == next_adapt);
     if (adapt_now) next_adapt += P.adapt_every;
     const bool adapt_do = adapt_now && nfac <= P.max_refactor;
-    auto reclassify = [&](int s, float& nb, float& ng) {
+    auto reclassify = [&](int s, float& nb, float& ng) __attribute__((always_inline)) {
       const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
       const bool actb = (zb[s] <= (RT)lb[s] || zb[s] >= (RT)ub[s]) && yb[s] != (RT)0;
       const bool actg = (zg[s] >= (RT)0) && yg[s] != (RT)0;
