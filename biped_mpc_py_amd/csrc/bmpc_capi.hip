@@ -227,14 +227,14 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
   return BMPC_OK;
 }
 
-template <int NP>
+template <int NP, int NW>
 int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                  const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
                  int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
                  hipStream_t st, const int32_t* order) {
   bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order};
   if (hd->warm_on && !dbg.assemble_only) {
-    const size_t need = (size_t)B * (5 * NP) * 12 * 6;       // [B][5 NP][12][6] doubles
+    const size_t need = (size_t)B * (5 * NP * NW) * 12 * 6;  // [B][5 NP NW][12][6] doubles
     if (need > hd->warm.n) hd->warm_valid = false;
     HIP_TRY(hd->warm.ensure(need));
     warm.buf = hd->warm.p;
@@ -245,10 +245,10 @@ int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, co
     warm.adapt_start = hd->params.warm_adapt_start;
   }
   if (dbg.prof)
-    hipLaunchKernelGGL((bmpc::stage_kernel_prof<NP>), dim3(B), dim3(64), 0, st, hd->dev, B, x_fb, foot, contact,
+    hipLaunchKernelGGL((bmpc::stage_kernel_prof<NP, NW>), dim3(B), dim3(64 * NW), 0, st, hd->dev, B, x_fb, foot, contact,
                        phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
   else
-    hipLaunchKernelGGL((bmpc::stage_kernel<NP>), dim3(B), dim3(64), 0, st, hd->dev, B, x_fb, foot, contact,
+    hipLaunchKernelGGL((bmpc::stage_kernel<NP, NW>), dim3(B), dim3(64 * NW), 0, st, hd->dev, B, x_fb, foot, contact,
                        phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
   HIP_TRY(hipGetLastError());
   if (warm.buf) { hd->warm_valid = true; hd->warm_batch = B; }
@@ -259,13 +259,13 @@ int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const ui
            const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
            int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
            hipStream_t st, const int32_t* order) {
-  // the stage-structured family (bmpc_stage.hip) is compiled per number of steps a lane owns, NP = ceil(h / 5)
   const bool dense_views = dbg.assemble_only && (dbg.Gt || dbg.qt);      // Gt, qt only exist on the dense path
   if (hd->path == BMPC_PATH_STAGE && !(dense_views && dense_horizon(hd->dev.h))) {
     if (dense_views) return fail(BMPC_ERR_INVALID, "Gt / qt views exist for h <= 20 only (h=%d never forms them)", hd->dev.h);
-    switch ((hd->dev.h + 4) / 5) {
-#define BMPC_CASE(NN) case NN: return launch_stage<NN>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order);
-      BMPC_CASE(2) BMPC_CASE(3) BMPC_CASE(4) BMPC_CASE(5) BMPC_CASE(6) BMPC_CASE(7) BMPC_CASE(8)
+    // compiled per (steps a lane owns, waves per instance): bmpc::stage_steps_per_lane / stage_waves
+    switch (10 * bmpc::stage_waves(hd->dev.h) + bmpc::stage_steps_per_lane(hd->dev.h)) {
+#define BMPC_CASE(NN, WW) case 10 * WW + NN: return launch_stage<NN, WW>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order);
+      BMPC_CASE(2, 1) BMPC_CASE(3, 1) BMPC_CASE(4, 1) BMPC_CASE(5, 1) BMPC_CASE(3, 2) BMPC_CASE(4, 2)
 #undef BMPC_CASE
       default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
     }

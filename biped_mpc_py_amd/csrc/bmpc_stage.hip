@@ -16,13 +16,16 @@
 //     penalties, f64 iterates and residual, f32 preconditioner: DESIGN.md sections 3, 4), so the iteration counts, the
 //     convergence record of the soaks and the parity numbers carry over; only the application of K^-1 differs.
 //
-// Thread map: ONE WAVE per instance.  Lane l = 12 q + 2 c + f: group q (5 groups; lanes 60..63 clone 56..59), component
-// c, foot f; the lane owns control variable c of foot f -- and state coordinate n = 2 c + f -- at the NP consecutive
-// steps j = q NP + s (s = 0 .. NP-1).  Steps past the horizon are PHANTOMS: they have their own LDS slots (the step
+// Thread map: ONE WAVE per instance up to h = 24, TWO from h = 26 (NW).  Lane l of wave w = 12 q + 2 c + f: group q (5
+// groups; lanes 60..63 clone 56..59), component c, foot f; the lane owns control variable c of foot f -- and state
+// coordinate n = 2 c + f -- at the NP consecutive steps j = (q NW + w) NP + s (s = 0 .. NP-1).  The 12 lanes of a step
+// always sit in one wave, so what they exchange stays wave-local; with two waves only the scans over the steps, the
+// two sequential passes and the Riccati recursion (run by wave 0) and the reductions cross a workgroup barrier.
+// (Two waves halve the steps a lane owns: at h = 40 one wave would need ~1000 registers and spill half of them.)  Steps past the horizon are PHANTOMS: they have their own LDS slots (the step
 // arrays hold 5 NP steps), read the inputs of step h - 1, do the same arithmetic as everybody else and are masked out
 // of everything that crosses steps (scans, the sequential passes, reductions, outputs) -- nothing is predicated on
 // them.  h is a launch parameter: the kernel is compiled per NP = ceil(h / 5) (NP = 2 .. 8: h = 8 .. 40).
-// No s_barrier anywhere: lanes of one wave exchange through LDS in program order (BMPC_WAVE_SYNC only fences the
+// Within a wave no s_barrier: lanes of one wave exchange through LDS in program order (BMPC_WAVE_SYNC only fences the
 // compiler) and through DPP.  The two sequential passes of a solve run on the 12 lanes of a DPP row, one state
 // coordinate per lane, as 12x12 mat-vecs whose operands arrive by row broadcast (no LDS round trip in the chain).
 // An instance needs no register-resident matrix, so many instances share a CU: the path is bound by the latency of
@@ -80,16 +83,16 @@ __device__ __forceinline__ float row_matvec12(float acc, float u, const float (&
 #endif
 }
 
-template <int NP>
+template <int NP, int NW>
 struct alignas(16) StageSmem {
-  static constexpr int HS = 5 * NP;            // step capacity
+  static constexpr int HS = 5 * NP * NW;       // step capacity
   struct FootBlock { float d[HS][6][6]; };
   // f64 6x6 scratch of the block algebra of ONE pass (5 steps), indexed by lane group
   struct Fac {
-    double M0[5][6][6];        // D0 -> Ka^-1 D0 W_0^-1
-    double M1[5][6][6];        // D1 -> Ka^-1
-    double M2[5][6][6];        // B = T' D1 T -> L~_0
-    double Ka[5][6][6];
+    double M0[5 * NW][6][6];   // D0 -> Ka^-1 D0 W_0^-1
+    double M1[5 * NW][6][6];   // D1 -> Ka^-1
+    double M2[5 * NW][6][6];   // B = T' D1 T -> L~_0
+    double Ka[5 * NW][6][6];
   };
   // exchange vectors of an iteration; never live together with the factor scratch
   struct Itv {
@@ -102,7 +105,8 @@ struct alignas(16) StageSmem {
     alignas(16) float xi[HS][12];      // state response Gam_t gamma
   };
   union alignas(16) { Fac fac; Itv itv; } u;
-  RT tot[2][5][12];            // group totals of the scans over the steps (double buffered)
+  RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
+  float red[2][5][NW];         // reductions across the waves
   // block-diagonal part of K^-1 (see bmpc_kernels.hip): L~ = L E^-1 (acceleration space), Kn = {Ka^-1, T Ka^-1}.
   // (no G images as in the dense kernels: an instance's LDS decides how many instances share a CU, and the step d
   //  is exchanged once per iteration instead)
@@ -168,7 +172,7 @@ __device__ __forceinline__ void ldl6_solve(const float (&s)[6][6], const float (
   }
 }
 
-template <int NP, bool PROF>
+template <int NP, int NW, bool PROF>
 __device__ __forceinline__ void
 stage_body(const DevParams& P, const int B,
            const float* __restrict__ x_fb, const float* __restrict__ foot,
@@ -178,15 +182,16 @@ stage_body(const DevParams& P, const int B,
            int32_t* __restrict__ iters_out, float* __restrict__ resid_out,
            int32_t* __restrict__ status_out, int32_t* __restrict__ nfactor_out,
            const DebugOut& dbg, const WarmArgs& warm) {
-  constexpr int HS = 5 * NP;
-  __shared__ StageSmem<NP> sm;
+  constexpr int HS = 5 * NP * NW;
+  constexpr int NT = 64 * NW;
+  __shared__ StageSmem<NP, NW> sm;
 
   if ((int)blockIdx.x >= B) return;
   const int inst = warm.order ? warm.order[blockIdx.x] : (int)blockIdx.x;
   const int H = P.h;                           // NP = ceil(H / 5) (checked on the host)
 #ifdef BMPC_EMU
   if (threadIdx.x == 0) std::memset(&sm, g_poison, sizeof(sm));
-  BMPC_WAVE_SYNC();
+  sync_workgroup();
 #endif
   // For many passes per lane the scheduler would interleave all of them (every pass body is independent of the others)
   // and run out of registers; a fence after every second pass keeps two in flight.
@@ -195,9 +200,15 @@ stage_body(const DevParams& P, const int B,
   long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #define BMPC_SSTAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
   if constexpr (PROF) t_start = clock64();
-  const int l = threadIdx.x;
+  const int lt = threadIdx.x;                  // thread of the workgroup
+  const int wv = NW > 1 ? lt >> 6 : 0;         // wave
+  const int l = lt & 63;                       // lane of the wave
   const int lc = l < 60 ? l : l - 4;           // lanes 60..63 clone lanes 56..59 (same indices, same data, same stores)
   const bool lane_real = l < 60;
+  // exchange between ALL lanes of the instance: the wave's own LDS ordering for one wave, a workgroup barrier for two
+  auto sync_all = [&]() __attribute__((always_inline)) {
+    if constexpr (NW > 1) { sync_workgroup(); } else { BMPC_WAVE_SYNC(); }
+  };
   const int q = lc / 12;                       // lane group: steps q NP .. q NP + NP - 1
   const int n = lc % 12;                       // state coordinate [e(3), p(3), w(3), v(3)] of the scans
   const int c = n >> 1;                        // component of the control variable v = [f(3), m(3)]
@@ -205,12 +216,13 @@ stage_body(const DevParams& P, const int B,
   const int hf = f;
   const int rn = (l & 15) < 12 ? (l & 15) : 11;   // state coordinate of the lane in the chains (DPP row; lanes 12..15 clone 11)
   const RT dt = (RT)P.dt;
+  const int qb = q * NW + wv;                   // block of NP consecutive steps this lane owns
   // steps of this lane (= LDS slots); past the horizon: phantoms with the inputs of the last step
   int js[NP], jg[NP];
   bool sreal[NP];
 #pragma unroll
   for (int s = 0; s < NP; ++s) {
-    js[s] = q * NP + s;
+    js[s] = (q * NW + wv) * NP + s;
     sreal[s] = js[s] < H;
     jg[s] = js[s] < H ? js[s] : H - 1;          // index into the per-step inputs in HBM
   }
@@ -218,18 +230,18 @@ stage_body(const DevParams& P, const int B,
   // (every lambda below is forced inline: one that is called from two places -- the scans, the exact rebuild -- is
   //  otherwise a real function inside a large module, and whatever it captures by reference then lives in scratch)
   // scans over the steps of one value per (lane, step), f64: the lane's NP steps are consecutive, so a scan is a local
-  // pass in registers plus one exchange of the 5 group totals.  Steps past the horizon contribute nothing.
-  int n_scan = 0;
+  // pass in registers plus one exchange of the 5 NW block totals.  Steps past the horizon contribute nothing.
+  int n_scan = 0, n_red = 0;
   auto group_add = [&](RT run, bool suffix) __attribute__((always_inline)) -> RT {
     RT (*tb)[12] = sm.tot[n_scan & 1];
     ++n_scan;
-    tb[q][n] = run;
-    BMPC_WAVE_SYNC();
+    tb[qb][n] = run;
+    sync_all();
     RT add = 0;
 #pragma unroll
-    for (int q2 = 0; q2 < 5; ++q2) {
+    for (int q2 = 0; q2 < 5 * NW; ++q2) {
       const RT t = tb[q2][n];
-      add += (suffix ? q2 > q : q2 < q) ? t : (RT)0;
+      add += (suffix ? q2 > qb : q2 < qb) ? t : (RT)0;
     }
     return add;
   };
@@ -361,7 +373,7 @@ stage_body(const DevParams& P, const int B,
   }
   if (dbg.assemble_only) return;
   // rows 0..5 of the forward matrices, [0, C_i] (constant over the factorisations), and 2 Q
-  for (int e = l; e < H * 72; e += 64) {
+  for (int e = lt; e < H * 72; e += NT) {
     const int i = e / 72, a = (e % 72) / 12, b = e % 12;
     float v = 0.f;
     if (b >= 6) {
@@ -370,7 +382,7 @@ stage_body(const DevParams& P, const int B,
     }
     sm.Mf[i][a][b] = v;
   }
-  if (l < 12) sm.q2[l] = 2.f * (float)P.Q[l];
+  if (lt < 12) sm.q2[lt] = 2.f * (float)P.Q[lt];
   if constexpr (PROF) t_setup = clock64() - t_start;
 
   // ------------------------------------------------------------------ C. constraint data (own variable, per step)
@@ -387,7 +399,7 @@ stage_body(const DevParams& P, const int B,
       ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
       ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
     }
-    if (l == 0) {
+    if (lt == 0) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) { sm.eyz[a] = ey[a]; sm.eyz[3 + a] = ez[a]; }
       float G[6][6];
@@ -424,7 +436,7 @@ stage_body(const DevParams& P, const int B,
     if constexpr (PROF) t_mark = clock64();
 #pragma unroll
     for (int s = 0; s < NP; ++s) sm.rvg[js[s]][f][c] = rvg[s];
-    BMPC_WAVE_SYNC();
+    sync_all();                                 // (also: the shared tables of the set-up, the iteration's exchange vectors are dead)
     int co = c;
     BMPC_OPAQUE(co);
     double mkd[6];
@@ -435,6 +447,7 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
     for (int a = 0; a < 3; ++a) { ey[a] = sm.eyz[a]; ez[a] = sm.eyz[3 + a]; }
     const double idt = 1.0 / (double)P.dt, mdt = (double)P.m / (double)P.dt;
+    const int qs = wv * 5 + q;                  // scratch slot of this lane group
     // ---- 6x6 block algebra in f64, one pass (5 steps) at a time through the scratch; bmpc_kernels.hip has the
     // derivation.  Here the wrench space is the ACCELERATION space a = E gamma: L~ = L E^-1, Ft = E^-T F E^-1.
 #pragma unroll 1
@@ -495,7 +508,7 @@ stage_body(const DevParams& P, const int B,
           m3[b] = fma(mkd[b], (double)R2v + (double)rvb[s], sacc);
         }
 #pragma unroll
-        for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[q][c][b] = m3[b];
+        for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[qs][c][b] = m3[b];
       }
       BMPC_WAVE_SYNC();
       const bool on0 = hf == 0, on1 = hf == 1;
@@ -503,7 +516,7 @@ stage_body(const DevParams& P, const int B,
       double ka[6];                               // row c of Ka^-1
       if (on0) {
         double yq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        row_times_mat6(Tcol, sm.u.fac.M1[q], yq);
+        row_times_mat6(Tcol, sm.u.fac.M1[qs], yq);
         double brow[6];                           // row c of B
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -511,7 +524,7 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
           for (int r = 0; r < 6; ++r) sacc = fma(yq[r], Tm[r][b], sacc);
           brow[b] = sacc;
-          sm.u.fac.Ka[q][c][b] = m3[b] + sacc;
+          sm.u.fac.Ka[qs][c][b] = m3[b] + sacc;
         }
         // U~ = E^-T W_0^-T D0,  W_0^-T = [[0, I], [I, [r_0]x]]: row c of E^-T W_0^-T is a combination of rows of W_0^-T
         double wti[6];
@@ -548,19 +561,19 @@ stage_body(const DevParams& P, const int B,
         }
 #pragma unroll
         for (int b = 0; b < 6; ++b) urow[b] = 0.0;
-        row_times_mat6(wti, sm.u.fac.M0[q], urow);
+        row_times_mat6(wti, sm.u.fac.M0[qs], urow);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) sm.u.fac.M2[q][c][b] = brow[b];
+        for (int b = 0; b < 6; ++b) sm.u.fac.M2[qs][c][b] = brow[b];
       }
       BMPC_WAVE_SYNC();                         // Ka, B published; D1 consumed
-      inv6_row(sm.u.fac.Ka[q], co, ka);           // both lanes of the row, each for itself: no exchange
+      inv6_row(sm.u.fac.Ka[qs], co, ka);           // both lanes of the row, each for itself: no exchange
       if (on0) {
 #pragma unroll
-        for (int b = 0; b < 6; ++b) sm.u.fac.M1[q][c][b] = ka[b];     // the whole Ka^-1 is needed for T Ka^-1 below
+        for (int b = 0; b < 6; ++b) sm.u.fac.M1[qs][c][b] = ka[b];     // the whole Ka^-1 is needed for T Ka^-1 below
       }
       double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
-      if (on0) row_times_mat6(ka, sm.u.fac.M2[q], xk);
-      if (on1) row_times_mat6(ka, sm.u.fac.M0[q], xk);
+      if (on0) row_times_mat6(ka, sm.u.fac.M2[qs], xk);
+      if (on1) row_times_mat6(ka, sm.u.fac.M0[qs], xk);
       BMPC_WAVE_SYNC();                         // B, D0 consumed; Ka^-1 published
       {
         const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
@@ -579,17 +592,17 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
           for (int b = 0; b < 6; ++b) {
             sm.LG[0].d[j][c][b] = (float)wE[b];
-            sm.u.fac.M2[q][c][b] = wE[b];         // L~_0 rows for Ft
+            sm.u.fac.M2[qs][c][b] = wE[b];         // L~_0 rows for Ft
           }
         } else {
 #pragma unroll
-          for (int b = 0; b < 6; ++b) sm.u.fac.M0[q][c][b] = wE[b];   // Ka^-1 D0 W_0^-1 E^-1 rows for L~_1
+          for (int b = 0; b < 6; ++b) sm.u.fac.M0[qs][c][b] = wE[b];   // Ka^-1 D0 W_0^-1 E^-1 rows for L~_1
         }
       }
       BMPC_WAVE_SYNC();
       if (on0) {
         double fv64[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        row_times_mat6(urow, sm.u.fac.M2[q], fv64);     // Ft = U~ L~_0
+        row_times_mat6(urow, sm.u.fac.M2[qs], fv64);     // Ft = U~ L~_0
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           sm.KG[0].d[j][c][b] = (float)ka[b];
@@ -598,8 +611,8 @@ stage_body(const DevParams& P, const int B,
       }
       if (on1) {
         double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        row_times_mat6(Trow, sm.u.fac.M0[q], sl);       // L~_1 = T (Ka^-1 D0 W_0^-1 E^-1)
-        row_times_mat6(Trow, sm.u.fac.M1[q], sk);       // T Ka^-1
+        row_times_mat6(Trow, sm.u.fac.M0[qs], sl);       // L~_1 = T (Ka^-1 D0 W_0^-1 E^-1)
+        row_times_mat6(Trow, sm.u.fac.M1[qs], sk);       // T Ka^-1
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           sm.LG[1].d[j][c][b] = (float)sl[b];
@@ -615,7 +628,8 @@ stage_body(const DevParams& P, const int B,
     //   R2  column jn of [M | Ft | I] solved against S = Ft + Pi22 (each lane its own LDL'): gain K, T = S^-1 Ft, S^-1
     //   R3  Schur complement Z = Pi - Pi[:,2] S^-1 Pi[2,:], cancellation-free in the (., 2) blocks: Z12 = Pi12 T, Z22 = Pi22 T
     //   R4  P = A' Z A:  P11 = Z11, P12 = Z11 C + Z12, P22 = C' P12 + Z12' C + Z22
-    {
+    sync_all();                                 // every step's Ft is in place
+    if (wv == 0) {                              // (wave-uniform)
       for (int e = l; e < 144; e += 64) sm.Pm[e / 12][e % 12] = 0.f;
       BMPC_WAVE_SYNC();
       const float dtf = (float)P.dt;
@@ -753,6 +767,7 @@ stage_body(const DevParams& P, const int B,
       }
 #undef BMPC_FT
     }
+    sync_all();
     if constexpr (PROF) t_ric += clock64() - t_mark;
   };
 
@@ -821,7 +836,7 @@ stage_body(const DevParams& P, const int B,
     // (e, p) part: sum_{i <= j} C_i xi2_{i-1}: the lanes n < 6 need xi2 of the step before, other coordinates
 #pragma unroll
     for (int s = 0; s < NP; ++s) sm.u.itv.lam[js[s]][n] = v2[s];
-    BMPC_WAVE_SYNC();
+    sync_all();                                 // (the step before may belong to another wave)
     RT v1[NP];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
@@ -855,6 +870,7 @@ stage_body(const DevParams& P, const int B,
       for (int k = 0; k < 5; ++k) ok = ok && (fabs(wv[s][k]) < 1.0e300);
     }
     ok = wave_umax(ok ? 0u : 1u) == 0u;        // all of the instance's state or none of it
+    if constexpr (NW > 1) ok = sync_workgroup_or(ok ? 0 : 1) == 0;
     if (ok) {
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
@@ -995,7 +1011,7 @@ stage_body(const DevParams& P, const int B,
       ddk[s] = f == 1 ? -dd : dd;
       BMPC_PASS_FENCE(s);
     }
-    BMPC_WAVE_SYNC();
+    sync_all();
     BMPC_SSTAMP(2)
     // --- P4: stage solve.  Backward pass: u = [p1; g], g = p2 - bt_i;  p <- p + Mf_i' u   (p_i = A_i' p_{i+1} - K_i' g_i);
     //     then w = Sinv g in parallel; forward pass: xi <- xi + Mf_i xi - [0; w_i]  (a_i = -K_i xi_{i-1} - w_i).
@@ -1020,24 +1036,26 @@ stage_body(const DevParams& P, const int B,
         sm.u.itv.gs[i][d6] = uu;
         p = row_matvec12(p, uu, cf);
       };
-      load_col(0, ca, va);
-      load_col(1, cb, vb);
       int k = 0;
+      if (wv == 0) {                            // (wave-uniform: the sequential passes run on one wave)
+        load_col(0, ca, va);
+        load_col(1, cb, vb);
 #pragma unroll 1
-      for (; k + 4 <= H; k += 4) {
-        load_col(k + 2, cc, vc);
-        load_col(k + 3, cd, vd);
-        BMPC_SCHED_BARRIER();
-        back_step(k, ca, va);
-        back_step(k + 1, cb, vb);
-        load_col(k + 4, ca, va);
-        load_col(k + 5, cb, vb);
-        BMPC_SCHED_BARRIER();
-        back_step(k + 2, cc, vc);
-        back_step(k + 3, cd, vd);
+        for (; k + 4 <= H; k += 4) {
+          load_col(k + 2, cc, vc);
+          load_col(k + 3, cd, vd);
+          BMPC_SCHED_BARRIER();
+          back_step(k, ca, va);
+          back_step(k + 1, cb, vb);
+          load_col(k + 4, ca, va);
+          load_col(k + 5, cb, vb);
+          BMPC_SCHED_BARRIER();
+          back_step(k + 2, cc, vc);
+          back_step(k + 3, cd, vd);
+        }
+        if (k < H) { back_step(k, ca, va); back_step(k + 1, cb, vb); }
       }
-      if (k < H) { back_step(k, ca, va); back_step(k + 1, cb, vb); }
-      BMPC_WAVE_SYNC();
+      sync_all();
       // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value); it replaces bt
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
@@ -1047,7 +1065,7 @@ stage_body(const DevParams& P, const int B,
         for (int m = 0; m < 6; ++m) acc = fmaf(sm.Sinv[j][c][m], sm.u.itv.gs[j][m], acc);
         sm.u.itv.bt[j][c] = acc;
       }
-      BMPC_WAVE_SYNC();
+      sync_all();
       float x = 0.f;
       auto load_row = [&](int k, float (&cf)[12], float& wvv) {
         const int i = k < H ? k : H - 1;
@@ -1065,25 +1083,27 @@ stage_body(const DevParams& P, const int B,
         x += inc;
         sm.u.itv.xi[i][rn] = x;
       };
-      load_row(0, ca, va);
-      load_row(1, cb, vb);
       k = 0;
+      if (wv == 0) {
+        load_row(0, ca, va);
+        load_row(1, cb, vb);
 #pragma unroll 1
-      for (; k + 4 <= H; k += 4) {
-        load_row(k + 2, cc, vc);
-        load_row(k + 3, cd, vd);
-        BMPC_SCHED_BARRIER();
-        fwd_step(k, ca, va);
-        fwd_step(k + 1, cb, vb);
-        load_row(k + 4, ca, va);
-        load_row(k + 5, cb, vb);
-        BMPC_SCHED_BARRIER();
-        fwd_step(k + 2, cc, vc);
-        fwd_step(k + 3, cd, vd);
+        for (; k + 4 <= H; k += 4) {
+          load_row(k + 2, cc, vc);
+          load_row(k + 3, cd, vd);
+          BMPC_SCHED_BARRIER();
+          fwd_step(k, ca, va);
+          fwd_step(k + 1, cb, vb);
+          load_row(k + 4, ca, va);
+          load_row(k + 5, cb, vb);
+          BMPC_SCHED_BARRIER();
+          fwd_step(k + 2, cc, vc);
+          fwd_step(k + 3, cd, vd);
+        }
+        if (k < H) { fwd_step(k, ca, va); fwd_step(k + 1, cb, vb); }
       }
-      if (k < H) { fwd_step(k, ca, va); fwd_step(k + 1, cb, vb); }
     }
-    BMPC_WAVE_SYNC();
+    sync_all();
     BMPC_SSTAMP(3)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
@@ -1191,6 +1211,22 @@ stage_body(const DevParams& P, const int B,
       float v5[5] = {rp, rs, nz, nx, chg};
 #pragma unroll
       for (int k = 0; k < 5; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
+      if constexpr (NW > 1) {                   // combine the waves (two buffers: a buffer is rewritten after another barrier)
+        float (*red)[NW] = sm.red[n_red & 1];
+        ++n_red;
+        if (l == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) red[k][wv] = v5[k];
+        }
+        sync_workgroup();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          unsigned m = __float_as_uint(red[k][0]);
+#pragma unroll
+          for (int w2 = 1; w2 < NW; ++w2) { const unsigned o = __float_as_uint(red[k][w2]); m = m > o ? m : o; }
+          v5[k] = __uint_as_float(m);
+        }
+      }
       if (check_now) {
         res_p = v5[0];
         res_s = v5[1];
@@ -1245,13 +1281,13 @@ stage_body(const DevParams& P, const int B,
       if (n == 0) so[12] = 1.0f;
     }
   }
-  if (PROF && dbg.prof && l == 0) {
+  if (PROF && dbg.prof && lt == 0) {
     long long* pr = dbg.prof + (size_t)inst * 16;
     pr[0] = t_setup; pr[1] = t_blocks; pr[2] = t_ric; pr[3] = clock64() - t_start; pr[4] = it; pr[5] = nfac;
 #pragma unroll
     for (int k = 0; k < 7; ++k) pr[8 + k] = t_ph[k];
   }
-  if (l == 0) {
+  if (lt == 0) {
     if (iters_out) iters_out[inst] = it;
     if (status_out) status_out[inst] = status;
     if (nfactor_out) nfactor_out[inst] = nfac;
@@ -1267,18 +1303,19 @@ stage_body(const DevParams& P, const int B,
       const float* __restrict__ mu_in, float* __restrict__ controls, float* __restrict__ states,                   \
       int32_t* __restrict__ iters_out, float* __restrict__ resid_out, int32_t* __restrict__ status_out,            \
       int32_t* __restrict__ nfactor_out, const DebugOut dbg, const WarmArgs warm
-// waves per SIMD the register allocation aims at: what the LDS image of an instance leaves room for
-template <int NP> struct StageOcc { static constexpr int WPE = 1; };
-template <int NP>
-__global__ void __launch_bounds__(64, StageOcc<NP>::WPE) stage_kernel(BMPC_STAGE_ARGS) {
-  stage_body<NP, false>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
-                        nfactor_out, dbg, warm);
+template <int NP, int NW>
+__global__ void __launch_bounds__(64 * NW) stage_kernel(BMPC_STAGE_ARGS) {
+  stage_body<NP, NW, false>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
+                            nfactor_out, dbg, warm);
 }
-template <int NP>
-__global__ void __launch_bounds__(64, StageOcc<NP>::WPE) stage_kernel_prof(BMPC_STAGE_ARGS) {
-  stage_body<NP, true>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
-                       nfactor_out, dbg, warm);
+template <int NP, int NW>
+__global__ void __launch_bounds__(64 * NW) stage_kernel_prof(BMPC_STAGE_ARGS) {
+  stage_body<NP, NW, true>(P, B, x_fb, foot, contact, phase, x_cmd, mu_in, controls, states, iters_out, resid_out, status_out,
+                           nfactor_out, dbg, warm);
 }
+// steps per lane and waves per instance for horizon h: one wave up to h = 24 (NP = ceil(h / 5)), two from h = 26
+__host__ __device__ constexpr int stage_waves(int h) { return h <= 24 ? 1 : 2; }
+__host__ __device__ constexpr int stage_steps_per_lane(int h) { return (h + 5 * stage_waves(h) - 1) / (5 * stage_waves(h)); }
 #undef BMPC_STAGE_ARGS
 
 }  // namespace bmpc

@@ -153,21 +153,24 @@ void run_h(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot
   }
 }
 
-template <int NP>
+template <int NP, int NW>
 void run_stage(const bmpc::DevParams& P, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states, int32_t* iters,
                float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg, const bmpc::WarmArgs& warm) {
+  constexpr int NT = 64 * NW;
   for (int b = 0; b < B; ++b) {
-    std::barrier<> bar(64), wbar(64);
+    std::barrier<> bar(NT);
     g_bar = &bar;
-    g_wbar[0] = &wbar;
-    for (int p = 0; p < 32; ++p) g_pair[p].store(0);
+    std::vector<std::unique_ptr<std::barrier<>>> wb;
+    for (int w = 0; w < NW; ++w) { wb.emplace_back(new std::barrier<>(64)); g_wbar[w] = wb.back().get(); }
+    for (int p = 0; p < NT / 2; ++p) g_pair[p].store(0);
+    g_or[0] = g_or[1] = 0;
     std::vector<std::thread> th;
-    for (int t = 0; t < 64; ++t)
+    for (int t = 0; t < NT; ++t)
       th.emplace_back([&, t]() {
         threadIdx.x = t;
         blockIdx.x = b;
-        bmpc::stage_kernel<NP>(P, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
+        bmpc::stage_kernel<NP, NW>(P, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm);
       });
     for (auto& x : th) x.join();
   }
@@ -189,7 +192,7 @@ bool inv3(const double* a, double* o) {
 
 extern "C" int bmpc_emu_threads(int h) { return h == 10 ? bmpc::Dims<10>::NT : (h == 16 ? bmpc::Dims<16>::NT : (h == 20 ? bmpc::Dims<20>::NT : -1)); }
 // doubles per instance of the warm-start buffer of the stage path
-extern "C" int bmpc_emu_stage_warm(int h) { return 5 * ((h + 4) / 5) * 12 * 6; }
+extern "C" int bmpc_emu_stage_warm(int h) { return 5 * bmpc::stage_steps_per_lane(h) * bmpc::stage_waves(h) * 12 * 6; }
 
 extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                               const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
@@ -214,9 +217,9 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta, p->warm_adapt_start};
   if (const char* e = std::getenv("BMPC_EMU_POISON")) g_poison = std::atoi(e);
   if (p->path == BMPC_PATH_STAGE) {
-    switch ((p->h + 4) / 5) {
-#define EMU_CASE(NN) case NN: run_stage<NN>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
-      EMU_CASE(2) EMU_CASE(3) EMU_CASE(4) EMU_CASE(5) EMU_CASE(6) EMU_CASE(7) EMU_CASE(8)
+    switch (10 * bmpc::stage_waves(p->h) + bmpc::stage_steps_per_lane(p->h)) {
+#define EMU_CASE(NN, WW) case 10 * WW + NN: run_stage<NN, WW>(d, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, warm); break;
+      EMU_CASE(2, 1) EMU_CASE(3, 1) EMU_CASE(4, 1) EMU_CASE(5, 1) EMU_CASE(3, 2) EMU_CASE(4, 2)
 #undef EMU_CASE
       default: return -1;
     }

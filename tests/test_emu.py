@@ -39,10 +39,12 @@ def test_kernel_source_on_cpu_matches_fixtures(name, idx):
         assert np.abs(o["foot_ref"].transpose(0, 2, 1) - d["foot_ref"][idx]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name,key,idx", [("cfg4_walking_h10", None, [3]), ("edge_cases_h10", None, [2]), ("cfg_hgen", 14, [0])])
+@pytest.mark.parametrize("name,key,idx", [("cfg4_walking_h10", None, [3]), ("edge_cases_h10", None, [2]), ("cfg_hgen", 14, [0]),
+                                          ("cfg_hgen", 26, [0])])
 def test_stage_kernel_source_on_cpu_matches_fixtures(name, key, idx):
     """The stage-structured kernel (bmpc_stage.hip: Riccati recursion, scans over the steps, phantom steps past the
-    horizon at h = 14, the DPP row broadcasts of the two passes emulated lane by lane) on the CPU against the fixtures."""
+    horizon at h = 14, the two-wave workgroup at h = 26, the DPP row broadcasts of the two passes emulated lane by lane) on
+    the CPU against the fixtures."""
     import __graft_entry__ as ge
     ge.build()
     import biped_mpc_py_amd as bm
