@@ -218,8 +218,10 @@ def cpu_baseline(s, h, dt, n_sample):
 
     def arg(i, full):
         # a time in the middle of schedule step `phase`, so that int(t // dt) % h (REF:99-100) gives it back
-        return (s["x_fb"][i].astype(float), (float(s["phase"][i]) + 0.5) * dt, s["foot"][i].astype(float), s["contact"][i],
-                s["x_cmd"][i] if s.get("use_x_cmd") else None, None if s["mu"] is None else s["mu"][i],
+        # the inputs cross the C ABI as fp32: the CPU path solves exactly the instance the GPU saw
+        r32 = lambda a: np.asarray(a, np.float32).astype(float)
+        return (r32(s["x_fb"][i]), (float(s["phase"][i]) + 0.5) * dt, r32(s["foot"][i]), s["contact"][i],
+                r32(s["x_cmd"][i]) if s.get("use_x_cmd") else None, None if s["mu"] is None else r32(s["mu"][i]),
                 h, s["half"], full)
 
     n1 = min(8, n_sample)
