@@ -58,7 +58,7 @@ int resolve_path(int h, int path) {
 //   force space   g_F[a]   = 2 (Q_p[a] (dt^2 / m)^2 S2 + Q_v[a] (dt / m)^2 h)
 // force-like rows see g_F plus the torque curvature through the lever arm of the nominal CoM height, moment-like rows
 // g_tau; the soft end of the spectrum is 2 R.  The penalty fields of bmpc_params are the values AT THE REFERENCE PROBLEM
-// (REF:22-48 defaults, h = 10) and scale with these ratios, so that weights, step length, mass, inertia and horizon can
+// (REF:22-48 defaults; horizon: the problem's own up to h = 20, else 10) and scale with these ratios, so that weights, step length, mass, inertia and horizon can
 // change without re-tuning (at h = 40 the stiff scale is 70 times the one at h = 10, and with
 // absolute ceilings the active rows of the early steps converge at 0.97 per iteration).
 struct CurvScales { double force, moment, soft; };
@@ -112,8 +112,14 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   }
   double pf = 1, pm = 1, pr = 1;               // curvature of this problem relative to the reference problem
   if (p.penalty_mode == BMPC_PENALTY_SCALED) {
+    // Up to h = 20 the reference problem has the horizon of the problem at hand: the absolute values were tuned and soaked
+    // at h = 10, 16 and 20 (10.5 M + 3.3 M instances), and the dense kernels' f32 sweep does not hold much larger ones
+    // (ceilings 8x higher at h = 20: 2 % of a standing batch lose convergence, some to NaNs, where the stage-structured
+    // kernels -- and the absolute values -- converge on every instance).  The long horizons (stage-structured kernels) follow
+    // the stiff end, which grows like sum k^2 ~ h^3, relative to h = 10 (h = 40: 72x before the cap below; absolute values
+    // there: 0.97 per iteration; relative to h = 20: 20 % more iterations and four times the non-converged instances).
     bmpc_params ref;
-    bmpc_default_params(&ref, 10);
+    bmpc_default_params(&ref, p.h <= 20 ? p.h : 10);
     const CurvScales c0 = curvature_scales(ref), c1 = curvature_scales(p);
     if (c0.force > 0 && c0.moment > 0 && c0.soft > 0 && c1.force > 0 && c1.moment > 0 && c1.soft > 0) {
       pf = c1.force / c0.force; pm = c1.moment / c0.moment; pr = c1.soft / c0.soft;
@@ -341,7 +347,11 @@ int bmpc_default_params(bmpc_params* p, int h) {
   p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 20.0;
   p->alpha = 1.6; p->eps_pri = 1e-7; p->eps_dua = 1e-7;
   p->max_iter = h <= 12 ? 400 : 600;       // (worst seen in the soaks: 240 at h = 10, 315 at h = 16 / 20 with the periods below)
-  p->check_every = 5; p->max_refactor = 24;
+  p->check_every = 5;
+  // (long horizons re-classify every 10 iterations: the 1-in-2000 instances that keep re-classifying need 25-35
+  //  factorisations and converge by iteration ~350; capped at 24 they freeze their penalties at iteration 240 and run
+  //  into max_iter)
+  p->max_refactor = h > 20 ? 48 : 24;
   // Re-classification period ~ (cost of a factorisation) / (cost of an iteration): 10.6 at h = 10, 15.6 at h = 16,
   // 21.5 at h = 20 (profiles/r02_cfg*_phase_cycles.txt).  Measured on MI355X (build_tmp-style A/B, round 2):
   // h = 16: period 20 from iteration 10 is 8 % faster than 10 / 10 (4.3 instead of 5.6 factorisations, 68 instead of

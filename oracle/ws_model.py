@@ -253,6 +253,15 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     hi = np.empty(12, dtp)
     hi[[0, 1, 2, 6, 7, 8, 9]] = P.rho_hi_f
     hi[[3, 4, 5, 10, 11]] = P.rho_hi_m
+    ds = getattr(P, "ds_unscaled", None)
+    if ds is not None:
+        # double-support steps keep the reference ceilings: an active row there sees the soft curvature (the other foot
+        # takes over), only single-support rows see the stiff one that grows with the horizon
+        other = contact[:, :, ::-1].astype(bool)[..., None]                # (B,h,2,1): the other foot stands
+        hi_ds = np.empty(12, dtp)
+        hi_ds[[0, 1, 2, 6, 7, 8, 9]] = ds[0]
+        hi_ds[[3, 4, 5, 10, 11]] = ds[1]
+        hi = np.where(other, np.minimum(hi, hi_ds), hi)                    # (B,h,2,12)
     rv = np.where(eq, rho_eq, rho0).astype(dtp)                            # (B,h,2,12)
     R2 = 2 * P.R.astype(dtp)
     Rblk = np.stack([np.concatenate([R2[0:3], R2[6:9]]), np.concatenate([R2[3:6], R2[9:12]])])  # (2,6)
