@@ -656,14 +656,13 @@ stage_body(const DevParams& P, const int B,
 #define BMPC_FT(a, b) sm.Mf[i][6 + (6 * (a) + (b)) / 12][(6 * (a) + (b)) % 12]
 #pragma unroll 1
       for (int i = H - 1; i >= 0; --i) {
+        // (every stage issues all its LDS loads first -- the scheduling barrier keeps the compiler from sinking each load
+        //  next to its use, which costs one exposed LDS round trip per group: a single wave has nobody to hide it)
         // R2
         {
           float S[6][6], rhs[6], x[6];
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) S[a][b] = BMPC_FT(a, b) + sm.Pm[6 + a][6 + b] + (a == b ? sm.q2[6 + a] : 0.f);
           {
+            float ftl[6][6], pml[6][6], qd[6];
             // right-hand side: column jn of [Pi21 | Pi21 C + Pi22 | Ft | I], by address
             const int k = jn < 12 ? (jn < 6 ? jn : jn - 6) : 0;
             int row[3];
@@ -672,14 +671,30 @@ stage_body(const DevParams& P, const int B,
             const float sel_m1 = jn < 6 ? 1.f : 0.f, sel_m2 = (jn >= 6 && jn < 12) ? 1.f : 0.f;
             const float sel_ft = (jn >= 12 && jn < 18) ? 1.f : 0.f;
             const int kf = (jn >= 12 && jn < 18) ? jn - 12 : 0, ki = jn >= 18 ? jn - 18 : -1;
+            float p21[6], p22[6], pc0[6], pc1[6], pc2[6], ftc[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              qd[a] = sm.q2[6 + a];
+#pragma unroll
+              for (int b2 = 0; b2 <= a; ++b2) { ftl[a][b2] = BMPC_FT(a, b2); pml[a][b2] = sm.Pm[6 + a][6 + b2]; }
+            }
             const float qk2 = sm.q2[6 + k];
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-              const float p21 = sm.Pm[6 + m][k];                       // Pi21[m][k]
-              const float p22 = sm.Pm[6 + m][6 + k] + (m == k ? qk2 : 0.f);
-              const float pc = sm.Pm[6 + m][row[0]] * cf[0] + sm.Pm[6 + m][row[1]] * cf[1] + sm.Pm[6 + m][row[2]] * cf[2];
-              const float ft = sm.Mf[i][6 + (6 * m + kf) / 12][(6 * m + kf) % 12];
-              rhs[m] = sel_m1 * p21 + sel_m2 * (pc + p22) + sel_ft * ft + (m == ki ? 1.f : 0.f);
+              p21[m] = sm.Pm[6 + m][k];                                 // Pi21[m][k]
+              p22[m] = sm.Pm[6 + m][6 + k];
+              pc0[m] = sm.Pm[6 + m][row[0]]; pc1[m] = sm.Pm[6 + m][row[1]]; pc2[m] = sm.Pm[6 + m][row[2]];
+              ftc[m] = sm.Mf[i][6 + (6 * m + kf) / 12][(6 * m + kf) % 12];
+            }
+            BMPC_SCHED_BARRIER();
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int b2 = 0; b2 <= a; ++b2) S[a][b2] = ftl[a][b2] + pml[a][b2] + (a == b2 ? qd[a] : 0.f);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+              const float pc = pc0[m] * cf[0] + pc1[m] * cf[1] + pc2[m] * cf[2];
+              rhs[m] = sel_m1 * p21[m] + sel_m2 * (pc + p22[m] + (m == k ? qk2 : 0.f)) + sel_ft * ftc[m] + (m == ki ? 1.f : 0.f);
             }
           }
           BMPC_WAVE_SYNC();                       // Ft_i consumed by every lane before K_i lands on it
@@ -697,22 +712,31 @@ stage_body(const DevParams& P, const int B,
         // and a few h = 40 instances in 4096 lose their convergence)
         {
           float zv[2];
+          float la[2][6], lb[2][6], ra_[2][6], rb_[2][6], pab[2], pba[2], qa2[2], qb2[2], rda[2], rdb[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const int blk = z_blk[t], a = z_a[t], b = z_b[t];
             const int rs = blk == 0 ? 12 : 6;
             const float* rbase = blk == 0 ? &sm.Mf[i][6][0] : &sm.Tm[0][0];
             const int ro = blk == 2 ? 6 : 0;
-            const float qa2 = sm.q2[ro + a], qb2 = sm.q2[ro + b];
-            const float* lra = &sm.Pm[ro + a][6];
-            const float* lrb = &sm.Pm[ro + b][6];
-            float v1 = blk == 0 ? sm.Pm[a][b] + (a == b ? qa2 : 0.f) : 0.f;
-            float v2 = blk == 0 ? sm.Pm[b][a] + (a == b ? qa2 : 0.f) : 0.f;
+            qa2[t] = sm.q2[ro + a]; qb2[t] = sm.q2[ro + b];
+            pab[t] = sm.Pm[a][b]; pba[t] = sm.Pm[b][a];
+            rda[t] = rbase[a * rs + b]; rdb[t] = rbase[b * rs + a];      // (the 2Q diagonal of Pi22 meets these)
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-              v1 = fmaf(lra[m] + ((blk == 2 && m == a) ? qa2 : 0.f), rbase[m * rs + b], v1);
-              v2 = fmaf(lrb[m] + ((blk == 2 && m == b) ? qb2 : 0.f), rbase[m * rs + a], v2);
+              la[t][m] = sm.Pm[ro + a][6 + m]; lb[t][m] = sm.Pm[ro + b][6 + m];
+              ra_[t][m] = rbase[m * rs + b]; rb_[t][m] = rbase[m * rs + a];
             }
+          }
+          BMPC_SCHED_BARRIER();
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int blk = z_blk[t], a = z_a[t], b = z_b[t];
+            const float dq = (blk == 0 && a == b) ? qa2[t] : 0.f;
+            float v1 = blk == 0 ? pab[t] + dq : 0.f, v2 = blk == 0 ? pba[t] + dq : 0.f;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { v1 = fmaf(la[t][m], ra_[t][m], v1); v2 = fmaf(lb[t][m], rb_[t][m], v2); }
+            if (blk == 2) { v1 = fmaf(qa2[t], rda[t], v1); v2 = fmaf(qb2[t], rdb[t], v2); }
             zv[t] = blk == 1 ? v1 : 0.5f * (v1 + v2);
           }
           BMPC_WAVE_SYNC();                       // (emulation: Z11 replaces Pi11 in place, all reads first)
@@ -727,37 +751,42 @@ stage_body(const DevParams& P, const int B,
         // R4
         {
           float p22 = 0.f, p12 = 0.f;
+          int ra[3], rb[3], rq[3];
+          float ca[3], cb[3], cq[3];
+          ctriple(i, pk, ra, ca);
+          ctriple(i, pk2, rb, cb);
+          ctriple(i, qk, rq, cq);
+          float z_v = sm.Zm[6 + pk][6 + pk2], z_w = sm.Zm[6 + pk2][6 + pk], z_q = sm.Zm[qa][6 + qk];
+          float zq12[3], zr12[3], zbk[3], zak[3], pab[3][3], pba[3][3], pq[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            zq12[t] = sm.Zm[ra[t]][6 + pk2];                            // Z12 part of P12[ra[t]][pk2]
+            zr12[t] = sm.Zm[rb[t]][6 + pk];                             //            P12[rb[t]][pk]
+            zbk[t] = zr12[t];                                           // (Z12' C)[pk][pk2] reads the same entries
+            zak[t] = zq12[t];
+            pq[t] = sm.Pm[qa][rq[t]];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { pab[t][u] = sm.Pm[ra[t]][rb[u]]; pba[t][u] = sm.Pm[rb[t]][ra[u]]; }
+          }
+          BMPC_SCHED_BARRIER();
           {
-            int ra[3], rb[3];
-            float ca[3], cb[3];
-            ctriple(i, pk, ra, ca);
-            ctriple(i, pk2, rb, cb);
             // entry (pk, pk2) and its mirror, averaged
-            float v = sm.Zm[6 + pk][6 + pk2], w = sm.Zm[6 + pk2][6 + pk];
+            float v = z_v, w = z_w;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-              float q12 = sm.Zm[ra[t]][6 + pk2];                       // P12[ra[t]][pk2] = Z12 + (Z11 C)
-              float r12 = sm.Zm[rb[t]][6 + pk];                        // P12[rb[t]][pk]
+              float q12 = zq12[t], r12 = zr12[t];
 #pragma unroll
-              for (int u = 0; u < 3; ++u) {
-                q12 = fmaf(sm.Pm[ra[t]][rb[u]], cb[u], q12);
-                r12 = fmaf(sm.Pm[rb[t]][ra[u]], ca[u], r12);
-              }
+              for (int u = 0; u < 3; ++u) { q12 = fmaf(pab[t][u], cb[u], q12); r12 = fmaf(pba[t][u], ca[u], r12); }
               v = fmaf(ca[t], q12, v);
-              v = fmaf(sm.Zm[rb[t]][6 + pk], cb[t], v);                // (Z12' C)[pk][pk2]
+              v = fmaf(zbk[t], cb[t], v);
               w = fmaf(cb[t], r12, w);
-              w = fmaf(sm.Zm[ra[t]][6 + pk2], ca[t], w);
+              w = fmaf(zak[t], ca[t], w);
             }
             p22 = 0.5f * (v + w);
-          }
-          {
-            int rb[3];
-            float cb[3];
-            ctriple(i, qk, rb, cb);
-            float v = sm.Zm[qa][6 + qk];
+            float vq = z_q;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) v = fmaf(sm.Pm[qa][rb[u]], cb[u], v);
-            p12 = v;
+            for (int u = 0; u < 3; ++u) vq = fmaf(pq[u], cq[u], vq);
+            p12 = vq;
           }
           BMPC_WAVE_SYNC();                       // (emulation: all reads of Pm / Zm before the stores)
           if (l < 36) sm.Pm[6 + pk][6 + pk2] = p22;
@@ -1055,6 +1084,7 @@ stage_body(const DevParams& P, const int B,
         }
         if (k < H) { back_step(k, ca, va); back_step(k + 1, cb, vb); }
       }
+      BMPC_SSTAMP(6)                            // (diagnostics: the backward pass alone)
       sync_all();
       // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value); it replaces bt
 #pragma unroll

@@ -102,7 +102,7 @@ def prof(B, h, path=2):
     print("h %d B %d path %d cycles mean: setup %.0f blocks %.0f riccati/sweeps %.0f total %.0f | iters %.1f nfac %.2f" % ((h, B, path) + tuple(pr[:, :6].mean(0))))
     it = pr[:, 3] - pr[:, 0] - pr[:, 1] - pr[:, 2]
     print("  per iteration %.0f ; blocks per factor %.0f ; riccati/sweep per factor %.0f" % ((it / pr[:, 4]).mean(), (pr[:, 1] / pr[:, 5]).mean(), (pr[:, 2] / pr[:, 5]).mean()))
-    names = ["adjoint+P1", "P2", "P3", "chains", "P5", "tail", "-"] if path == 2 else ["P0", "P1", "P2", "P3", "P4", "P5", "tail"]
+    names = ["adjoint+P1", "P2", "P3", "w+forward", "P5", "tail", "backward"] if path == 2 else ["P0", "P1", "P2", "P3", "P4", "P5", "tail"]
     print("  phases, cycles per iteration: " + " ".join("%s %.0f" % (n, v) for n, v in zip(names, (pr[:, 8:15] / pr[:, 4:5]).mean(0))))
 
 
