@@ -194,9 +194,11 @@ def _cpu_one(args):
     t0 = time.perf_counter()
     sp = orc.build_sparse_qp(x, t, f, mpc, bp, c, half=half, mu_steps=mu)
     t1 = time.perf_counter()
-    z, _, _, _ = orc.solve_qp(sp["P"], sp["q"], sp["G"], sp["h"], sp["A"], sp["b"], 13 * h, polish=full)
+    z, _, _, info = orc.solve_qp(sp["P"], sp["q"], sp["G"], sp["h"], sp["A"], sp["b"], 13 * h, polish=full)
     t2 = time.perf_counter()
-    return z[13 * h:].reshape(h, 12), t1 - t0, t2 - t1
+    k = info["kkt"]
+    certified = bool(info["polished"]) and max(k["stationarity"], k["primal_ineq"], k["complementarity"]) <= 1e-7
+    return z[13 * h:].reshape(h, 12), t1 - t0, t2 - t1, certified
 
 
 def _log(msg):
@@ -247,6 +249,7 @@ def cpu_baseline(s, h, dt, n_sample):
         wallf = time.perf_counter() - t0
     _log("cpu_baseline: done")
     ctrl_full = np.stack([o[0] for o in outf])
+    cert_full = np.array([o[3] for o in outf], bool)
     ctrl_plain = np.stack([o[0] for o in out])
     cb = dict(value=n_sample / wall, unit="solves/s", cores=cores, kind="port",
               single_core_ms={"assembly": asm_ms, "solve": sol_ms, "total": asm_ms + sol_ms},
@@ -257,7 +260,7 @@ def cpu_baseline(s, h, dt, n_sample):
                      f"from {n1} instances on one worker with the others idle",
               oracle_with_polish={"value": nfull / wallf, "unit": "solves/s", "instances": nfull,
                                   "note": "oracle.solve_mpc as the parity tests use it (IPM + active-set polish + certificate)"})
-    return ctrl_full, ctrl_plain, cb
+    return ctrl_full, ctrl_plain, cb, cert_full
 
 
 class _StdoutToStderr:
@@ -574,7 +577,7 @@ def run_rank(args):
             n = min(cpu_sample, B)
             got = o_u.cpu().numpy().astype(np.float64)
             try:
-                ref_full, ref_plain, cb = cpu_baseline(s, h, mpc.dt, n)
+                ref_full, ref_plain, cb, cert = cpu_baseline(s, h, mpc.dt, n)
             except Exception as e:          # a stuck or failed worker pool must not cost the GPU measurement
                 _log(f"cpu_baseline failed: {type(e).__name__}: {e}")
                 line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
@@ -586,8 +589,11 @@ def run_rank(args):
                 k = len(b)
                 return np.abs(a[:k] - b).reshape(k, -1).max(1) / np.maximum(1.0, np.abs(b).reshape(k, -1).max(1))
             r_full, r_plain = rel(got, ref_full), rel(got, ref_plain)
+            n_unc = int((~cert).sum())               # references whose own KKT certificate is not tight are not a yardstick
+            r_full = r_full[cert] if cert.any() else r_full
             line["cpu_baseline"] = cb
             line["parity"] = {"max_rel_err_vs_oracle": float(r_full.max()), "instances": int(len(r_full)),
+                              "oracle_uncertified": n_unc,
                               "p99.9_rel_err_vs_oracle": float(np.quantile(r_full, 0.999)),
                               "p99.9_rel_err_vs_plain_ipm": float(np.quantile(r_plain, 0.999)),
                               "max_rel_err_vs_plain_ipm": float(r_plain.max()), "instances_plain_ipm": int(len(r_plain)),

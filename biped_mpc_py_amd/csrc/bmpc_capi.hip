@@ -140,6 +140,11 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     rho_eq = std::fmin(rho_eq, top); hi_f = std::fmin(hi_f, top); hi_m = std::fmin(hi_m, top);
     rho0 = std::fmin(rho0, hi_f);
   }
+  {
+    double rmin = p.R[0];
+    for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p.R[i]);
+    d->r2min = (float)(2 * rmin);
+  }
   d->rho = (float)rho0;
   d->rho_eq = (float)rho_eq;
   d->rho_lo = (float)rho_lo;

@@ -106,7 +106,7 @@ struct alignas(16) StageSmem {
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
-  float red[2][5][NW];         // reductions across the waves
+  float red[2][6][NW];         // reductions across the waves
   // block-diagonal part of K^-1 (see bmpc_kernels.hip): L~ = L E^-1 (acceleration space), Kn = {Ka^-1, T Ka^-1}.
   // (no G images as in the dense kernels: an instance's LDS decides how many instances share a CU, and the step d
   //  is exchanged once per iteration instead)
@@ -1136,7 +1136,7 @@ stage_body(const DevParams& P, const int B,
     sync_all();
     BMPC_SSTAMP(3)
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
-    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f;
+    float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f, slw = 0.f;
     const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // wave-uniform
     float dstep[NP];                          // d_f[c] = (null-space part) + L~ a
 #pragma unroll
@@ -1202,6 +1202,11 @@ stage_body(const DevParams& P, const int B,
       }
       if (check_now && sreal[s]) {
         rp = fmaxf(rp, fmaxf(fabsf((float)st_pb), fabsf((float)st_pg)));
+        {
+          const bool actb = (zb[s] <= (RT)lb[s] || zb[s] >= (RT)ub[s]) && yb[s] != (RT)0;
+          const bool actg = (zg[s] >= (RT)0) && yg[s] != (RT)0;
+          slw = fmaxf(slw, fmaxf((actb || eqb[s]) ? 0.f : rvb[s] * fabsf((float)st_pb), actg ? 0.f : rvg[s] * fabsf((float)st_pg)));
+        }
         nz = fmaxf(nz, fmaxf(fabsf((float)xto), fabsf((float)ztg)));
         rs = fmaxf(rs, fabsf((float)(xto - xo[s])));
         // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
@@ -1228,6 +1233,7 @@ stage_body(const DevParams& P, const int B,
       nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kap, hib) : fmaxf(rvb[s] / kap, P.rho_lo));
       ng = actg ? fminf(rvg[s] * kap, hig) : fmaxf(rvg[s] / kap, P.rho_lo);
     };
+    bool force_adapt = false;
     if (check_now || adapt_do) {
       float chg = 0.f;
       if (adapt_do) {
@@ -1238,19 +1244,22 @@ stage_body(const DevParams& P, const int B,
           chg = (sreal[s] && ((nb != rvb[s]) | (ng != rvg[s]))) ? 1.f : chg;
         }
       }
-      float v5[5] = {rp, rs, nz, nx, chg};
+      // (see bmpc_kernels.hip: the third stopping test -- the pull rho |z~ - z| of the inactive rows against the softest
+      //  curvature; an instance that fails it re-classifies at once instead of stopping)
+      constexpr float SLOW_TOL = 1.0e-5f;
+      float v5[6] = {rp, rs, nz, nx, chg, slw};
 #pragma unroll
-      for (int k = 0; k < 5; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
+      for (int k = 0; k < 6; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
       if constexpr (NW > 1) {                   // combine the waves (two buffers: a buffer is rewritten after another barrier)
         float (*red)[NW] = sm.red[n_red & 1];
         ++n_red;
         if (l == 0) {
 #pragma unroll
-          for (int k = 0; k < 5; ++k) red[k][wv] = v5[k];
+          for (int k = 0; k < 6; ++k) red[k][wv] = v5[k];
         }
         sync_workgroup();
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 6; ++k) {
           unsigned m = __float_as_uint(red[k][0]);
 #pragma unroll
           for (int w2 = 1; w2 < NW; ++w2) { const unsigned o = __float_as_uint(red[k][w2]); m = m > o ? m : o; }
@@ -1262,7 +1271,9 @@ stage_body(const DevParams& P, const int B,
         res_s = v5[1];
         const float tol_p = P.eps_pri * fmaxf(1.f, v5[2]), tol_s = P.eps_dua * fmaxf(1.f, v5[3]);
         const bool bad = !(v5[0] == v5[0]) || !(v5[1] == v5[1]) || !(v5[3] < 3.0e38f);
-        const bool done = v5[0] <= tol_p && v5[1] <= tol_s;
+        const bool small = v5[0] <= tol_p && v5[1] <= tol_s;
+        const bool done = small && !(v5[5] > SLOW_TOL * P.r2min * fmaxf(1.f, v5[3]));
+        force_adapt = small && !done && !bad && nfac <= P.max_refactor && it < P.max_iter;
         const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
         next_check += far ? 2 * check_every : check_every;
         const bool rebuild = it >= next_refresh;
@@ -1271,7 +1282,7 @@ stage_body(const DevParams& P, const int B,
         if (bad) { status = 2; break; }
         if (done) { status = 0; break; }
       }
-      if (adapt_do && v5[4] > 0.f) {
+      if ((adapt_do && v5[4] > 0.f) || force_adapt) {
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
           float nb, ng;

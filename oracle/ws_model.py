@@ -323,6 +323,26 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
             sc_p = np.maximum(np.abs(zt).reshape(B, -1).max(1), 1)
             sc_d = np.maximum(np.abs(xt).reshape(B, -1).max(1), 1)
             done = (rp <= P.eps_pri * sc_p) & (rs <= P.eps_dua * sc_d)
+            guard = getattr(P, "slow_guard", 0.0)
+            if guard:
+                # An inactive row whose penalty is still far above the floor follows at 1 - alpha c / rho per iteration, c the
+                # curvature it sees: the residuals are then small because the steps are, not because the iterate has arrived.
+                # What such a row still pulls with, rho |z~ - z|, equals c |error|; bounded against the softest curvature
+                # 2 R_min it bounds the error.  An instance that fails this test does not stop; it re-classifies at once.
+                actn = ((zn <= lr) | (zn >= ur)) & (yn != 0)
+                pull = np.where((~actn) & (~eq), rvr * np.abs(zt - zn), 0).reshape(B, -1).max(1)
+                slow_any = pull > guard * 2 * P.R.min() * sc_d
+                force = done & slow_any & active
+                done = done & ~slow_any
+                if force.any() and P.kappa:
+                    kap = np.where(n_factor <= 10, P.kappa, np.where(n_factor <= 16, P.kappa ** 0.5, P.kappa ** 0.25)).astype(dtp)[:, None, None, None]
+                    rvc = np.clip(rv, dt_(P.rho_lo), hi)
+                    rnew = np.where(eq, rho_eq, np.where(actn, np.minimum(rvc * kap, hi), np.maximum(rvc / kap, dt_(P.rho_lo)))).astype(dtp)
+                    ch = force & (rnew != rv).reshape(B, -1).any(1) & (n_factor <= P.max_refactor)
+                    if ch.any():
+                        rv = np.where(ch[:, None, None, None], rnew, rv)
+                        L, Na, V = fac(rv)
+                        n_factor += ch
             newly = active & done
             it_done[newly] = it + 1
             if iters is None:

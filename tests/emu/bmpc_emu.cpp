@@ -206,6 +206,11 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.dt = p->dt; d.kv = p->kv; d.m = p->m; d.g = p->g; d.mu = p->mu;
   d.lt = p->lt - 0.01; d.lh = p->lh - 0.02; d.alpha = p->alpha;
   for (int i = 0; i < 12; ++i) { d.x_cmd[i] = p->x_cmd[i]; d.Q[i] = p->Q[i]; d.R2[i] = 2.0 * p->R[i]; }
+  {
+    double rmin = p->R[0];
+    for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p->R[i]);
+    d.r2min = (float)(2 * rmin);
+  }
   if (!inv3(p->I, d.Iinv)) return -1;
   for (int i = 0; i < 3; ++i) {
     d.f_max[i] = p->f_max[i]; d.f_min[i] = p->f_min[i]; d.tau_max[i] = p->tau_max[i]; d.tau_min[i] = p->tau_min[i];
