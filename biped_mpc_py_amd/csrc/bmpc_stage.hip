@@ -76,7 +76,7 @@ __device__ __forceinline__ float row_matvec12(float acc, float u, const float (&
       "v_fmac_f32_dpp %0, %3, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
       "v_fmac_f32_dpp %1, %3, %14 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
       "v_fmac_f32_dpp %2, %3, %15 row_newbcast:11 row_mask:0xf bank_mask:0xf"
-      : "+v"(a0), "+v"(a1), "+v"(a2)
+      : "+&v"(a0), "+&v"(a1), "+&v"(a2)      // early clobber: acc may hold the same value as u and must not share its register
       : "v"(u), "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]), "v"(cf[8]),
         "v"(cf[9]), "v"(cf[10]), "v"(cf[11]));
   return a0 + (a1 + a2);
@@ -103,6 +103,7 @@ struct alignas(16) StageSmem {
     float gs[HS][8];           // g = p2 - bt of the backward pass (slot 6: dump for the lanes that hold no g)
     float av[HS][8];           // accelerations a = E gamma of the solve (slot 6: dump)
     alignas(16) float xi[HS][12];      // state response Gam_t gamma
+    alignas(16) float rbw[HS][12];     // backward pass: r_i = M_i' [0; bt_i]
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
@@ -112,9 +113,18 @@ struct alignas(16) StageSmem {
   //  is exchanged once per iteration instead)
   alignas(16) FootBlock LG[2];
   alignas(16) FootBlock KG[2];
-  // stage solve: forward matrix Mf_i = [[0, C_i], [-K_i]] (12 x 12; rows 6..11 = minus the Riccati gain) and S_i^-1.
-  // Until the recursion reaches step i, rows 6..8 of Mf_i hold the stage cost Ft_i (36 floats) of the block algebra.
-  alignas(16) float Mf[HS][12][12];
+  // stage solve.  Step i maps the state by F_i = I + M_i, M_i = [[0, C_i], [-K_i]] (12 x 12): the Riccati gain is kept as
+  // Kn_i = -K_i (6 x 12; until the recursion reaches step i its first 36 floats hold the stage cost Ft_i of the block
+  // algebra), C_i = dt blkdiag(Rinv_i, I) as its 3x3 block Cr_i.  The steps are grouped into NB <= 4 NW blocks of S
+  // consecutive steps, one per DPP row of the instance, with the block products A_b = F_{last} .. F_{first}.
+  static constexpr int NBM = 4 * NW;
+  alignas(16) float Kn[HS][6][12];
+  alignas(16) float Cr[HS][12];
+  alignas(16) float Ab[NBM][12][12];
+  alignas(16) float blkv[NBM][12];    // per block: the affine part of the block map
+  alignas(16) float blkp[NBM][12];    // per block: the state entering it
+  alignas(16) float zblk[72];         // zeros (coefficients of steps past the horizon)
+  alignas(16) float dtrow[3][12];     // rows 3..5 of M_i (the same for every step): dt in column 9 + k
   alignas(16) float Sinv[HS][6][6];
   alignas(16) float Pm[12][12];   // Riccati recursion: cost-to-go
   alignas(16) float Zm[12][12];   //                    Schur complement (blocks 12, 22; Z11 replaces Pi11 in Pm)
@@ -214,7 +224,8 @@ stage_body(const DevParams& P, const int B,
   const int c = n >> 1;                        // component of the control variable v = [f(3), m(3)]
   const int f = n & 1;                         // foot
   const int hf = f;
-  const int rn = (l & 15) < 12 ? (l & 15) : 11;   // state coordinate of the lane in the chains (DPP row; lanes 12..15 clone 11)
+  const int rn_lane = (l & 15) < 12 ? (l & 15) : 11;
+  const int rn = rn_lane;   // state coordinate of the lane in the chains (DPP row; lanes 12..15 clone 11)
   const RT dt = (RT)P.dt;
   const int qb = q * NW + wv;                   // block of NP consecutive steps this lane owns
   // steps of this lane (= LDS slots); past the horizon: phantoms with the inputs of the last step
@@ -372,16 +383,13 @@ stage_body(const DevParams& P, const int B,
     err[s] = e0[s];                            // x = 0
   }
   if (dbg.assemble_only) return;
-  // rows 0..5 of the forward matrices, [0, C_i] (constant over the factorisations), and 2 Q
-  for (int e = lt; e < H * 72; e += NT) {
-    const int i = e / 72, a = (e % 72) / 12, b = e % 12;
-    float v = 0.f;
-    if (b >= 6) {
-      const int k = b - 6;
-      v = (a < 3 && k < 3) ? (float)(dt * sm.Rv[i][3 * (a < 3 ? a : 0) + (k < 3 ? k : 0)]) : (a == k ? (float)dt : 0.f);
-    }
-    sm.Mf[i][a][b] = v;
+  // the rotational block of C_i = dt blkdiag(Rinv_i, I) (constant over the factorisations), zeros, and 2 Q
+  for (int e = lt; e < H * 12; e += NT) {
+    const int i = e / 12, k = e % 12;
+    sm.Cr[i][k] = k < 9 ? (float)(dt * sm.Rv[i][k]) : 0.f;
   }
+  for (int e = lt; e < 72; e += NT) sm.zblk[e] = 0.f;
+  for (int e = lt; e < 36; e += NT) sm.dtrow[e / 12][e % 12] = (e % 12 == 9 + e / 12) ? (float)P.dt : 0.f;
   if (lt < 12) sm.q2[lt] = 2.f * (float)P.Q[lt];
   if constexpr (PROF) t_setup = clock64() - t_start;
 
@@ -431,6 +439,44 @@ stage_body(const DevParams& P, const int B,
     rvb[s] = eqb[s] ? P.rho_eq : P.rho; rvg[s] = P.rho;
     irvb[s] = (RT)1 / (RT)rvb[s]; irvg[s] = (RT)1 / (RT)rvg[s];
   }
+
+  // Blocks of the stage solve: S consecutive steps per block, NB <= 4 NW blocks, block `sb` on DPP row `sb` of the instance.
+#ifdef BMPC_EMU
+#define BMPC_OPAQUE(x) do { } while (0)
+#else
+#define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+#define BMPC_BLOCK_GEOMETRY                                                                                   \
+  const int BS = (H + 4 * NW - 1) / (4 * NW); /* steps per block */                                           \
+  const int NB = (H + BS - 1) / BS;           /* blocks */                                                    \
+  const int sb = wv * 4 + (l >> 4);           /* block of this lane's DPP row */
+  // row rn / column rn of M_i = F_i - I = [[0, C_i], [Kn_i]] for the lane's coordinate, zero for a step past the horizon
+  // (rows 6..11 and their part of a column are Kn_i; the rest is C_i: its 3x3 block Cr_i and dt on the diagonal)
+  // Loads only, no arithmetic on what was read (a product or a select on a loaded value would make the prefetch of the
+  // next step wait for LDS inside this one): the zero parts come from `zblk`, the constant rows from `dtrow`, by address.
+  auto m_row = [&](int rn, int i, bool ok, float (&cf)[12]) __attribute__((always_inline)) {
+    const float* kp = rn >= 6 ? &sm.Kn[i][rn - 6][0] : rn >= 3 ? &sm.dtrow[rn - 3][0] : &sm.zblk[0];
+    kp = ok ? kp : &sm.zblk[0];
+    const float* cp = (ok && rn < 3) ? &sm.Cr[i][3 * rn] : kp + 6;
+    const float4 v0 = *reinterpret_cast<const float4*>(kp);
+    const float2 v1 = *reinterpret_cast<const float2*>(kp + 4);
+    const float2 v2 = *reinterpret_cast<const float2*>(kp + 10);
+    cf[0] = v0.x; cf[1] = v0.y; cf[2] = v0.z; cf[3] = v0.w; cf[4] = v1.x; cf[5] = v1.y;
+    cf[6] = cp[0]; cf[7] = cp[1]; cf[8] = cp[2];
+    cf[9] = kp[9]; cf[10] = v2.x; cf[11] = v2.y;
+  };
+  auto m_col = [&](int rn, int i, bool ok, float (&cf)[12]) __attribute__((always_inline)) {
+    const float dtf_c = (float)P.dt;
+    const float* kp = ok ? &sm.Kn[i][0][rn] : &sm.zblk[rn];
+    const float* cp = (ok && rn >= 6 && rn < 9) ? &sm.Cr[i][rn - 6] : &sm.zblk[0];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      cf[a] = cp[3 * a];
+      cf[3 + a] = (ok && rn == 9 + a) ? dtf_c : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) cf[6 + m] = kp[12 * m];
+  };
 
   auto factor = [&]() __attribute__((always_inline)) {
     if constexpr (PROF) t_mark = clock64();
@@ -606,7 +652,7 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           sm.KG[0].d[j][c][b] = (float)ka[b];
-          sm.Mf[j][6 + c / 2][6 * (c % 2) + b] = (float)fv64[b];      // Ft[c][b], parked in rows 6..8 of Mf_j
+          sm.Kn[j][c / 2][6 * (c % 2) + b] = (float)fv64[b];          // Ft[c][b], parked in the first 36 floats of Kn_j
         }
       }
       if (on1) {
@@ -649,11 +695,11 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           row[t] = k < 3 ? t : k;
-          cf[t] = k < 3 ? sm.Mf[i][t][6 + k] : (t == 0 ? dtf : 0.f);
+          cf[t] = k < 3 ? sm.Cr[i][3 * t + k] : (t == 0 ? dtf : 0.f);
         }
       };
-      // Ft_i[a][b] sits in rows 6..8 of Mf_i until K_i overwrites them
-#define BMPC_FT(a, b) sm.Mf[i][6 + (6 * (a) + (b)) / 12][(6 * (a) + (b)) % 12]
+      // Ft_i[a][b] sits in the first 36 floats of Kn_i until the gain overwrites them
+#define BMPC_FT(a, b) sm.Kn[i][(6 * (a) + (b)) / 12][(6 * (a) + (b)) % 12]
 #pragma unroll 1
       for (int i = H - 1; i >= 0; --i) {
         // (every stage issues all its LDS loads first -- the scheduling barrier keeps the compiler from sinking each load
@@ -684,7 +730,7 @@ stage_body(const DevParams& P, const int B,
               p21[m] = sm.Pm[6 + m][k];                                 // Pi21[m][k]
               p22[m] = sm.Pm[6 + m][6 + k];
               pc0[m] = sm.Pm[6 + m][row[0]]; pc1[m] = sm.Pm[6 + m][row[1]]; pc2[m] = sm.Pm[6 + m][row[2]];
-              ftc[m] = sm.Mf[i][6 + (6 * m + kf) / 12][(6 * m + kf) % 12];
+              ftc[m] = sm.Kn[i][(6 * m + kf) / 12][(6 * m + kf) % 12];
             }
             BMPC_SCHED_BARRIER();
 #pragma unroll
@@ -699,8 +745,8 @@ stage_body(const DevParams& P, const int B,
           }
           BMPC_WAVE_SYNC();                       // Ft_i consumed by every lane before K_i lands on it
           ldl6_solve(S, rhs, x);
-          // K -> rows 6..11 of Mf_i (negated), T -> Tm, S^-1 -> Sinv_i: one store address per lane
-          float* dst = jn < 12 ? &sm.Mf[i][6][jn] : (jn < 18 ? &sm.Tm[0][jn - 12] : &sm.Sinv[i][0][jn - 18]);
+          // K -> Kn_i (negated), T -> Tm, S^-1 -> Sinv_i: one store address per lane
+          float* dst = jn < 12 ? &sm.Kn[i][0][jn] : (jn < 18 ? &sm.Tm[0][jn - 12] : &sm.Sinv[i][0][jn - 18]);
           const int stride = jn < 12 ? 12 : 6;
           const float sg = jn < 12 ? -1.f : 1.f;
 #pragma unroll
@@ -717,7 +763,7 @@ stage_body(const DevParams& P, const int B,
           for (int t = 0; t < 2; ++t) {
             const int blk = z_blk[t], a = z_a[t], b = z_b[t];
             const int rs = blk == 0 ? 12 : 6;
-            const float* rbase = blk == 0 ? &sm.Mf[i][6][0] : &sm.Tm[0][0];
+            const float* rbase = blk == 0 ? &sm.Kn[i][0][0] : &sm.Tm[0][0];
             const int ro = blk == 2 ? 6 : 0;
             qa2[t] = sm.q2[ro + a]; qb2[t] = sm.q2[ro + b];
             pab[t] = sm.Pm[a][b]; pba[t] = sm.Pm[b][a];
@@ -795,6 +841,27 @@ stage_body(const DevParams& P, const int B,
         BMPC_WAVE_SYNC();
       }
 #undef BMPC_FT
+    }
+    sync_all();
+    // ---- block products A_b = F_last .. F_first, one block per DPP row (row rn of A_b in 12 registers; a step multiplies
+    // from the left: column c of the new A is (I + M_i) times column c of the old one, a row-broadcast mat-vec per column)
+    {
+      BMPC_BLOCK_GEOMETRY
+      float A[12];
+#pragma unroll
+      for (int cidx = 0; cidx < 12; ++cidx) A[cidx] = (rn == cidx) ? 1.f : 0.f;
+#pragma unroll 1
+      for (int t = 0; t < BS; ++t) {
+        const int i = sb * BS + t;
+        const bool ok = sb < NB && i < H;
+        float cf[12];
+        m_row(rn, i < H ? i : H - 1, ok, cf);
+#pragma unroll
+        for (int cidx = 0; cidx < 12; ++cidx) A[cidx] = row_matvec12(A[cidx], A[cidx], cf);
+      }
+#pragma unroll
+      for (int cidx = 0; cidx < 12; cidx += 4)
+        *reinterpret_cast<float4*>(&sm.Ab[sb][rn][cidx]) = float4{A[cidx], A[cidx + 1], A[cidx + 2], A[cidx + 3]};
     }
     sync_all();
     if constexpr (PROF) t_ric += clock64() - t_mark;
@@ -1042,49 +1109,119 @@ stage_body(const DevParams& P, const int B,
     }
     sync_all();
     BMPC_SSTAMP(2)
-    // --- P4: stage solve.  Backward pass: u = [p1; g], g = p2 - bt_i;  p <- p + Mf_i' u   (p_i = A_i' p_{i+1} - K_i' g_i);
-    //     then w = Sinv g in parallel; forward pass: xi <- xi + Mf_i xi - [0; w_i]  (a_i = -K_i xi_{i-1} - w_i).
-    //     One state coordinate per lane of a DPP row, operands by row broadcast: no LDS round trip in the chain.
+    // --- P4: stage solve.  A step maps the costate by p_i = F_i' p_{i+1} - r_i (r_i = M_i' [0; bt_i], g_i = p2_{i+1} - bt_i) and
+    //     the state by xi_i = F_i xi_{i-1} - [0; w_i] (w = Sinv g; a_i = xi2_i - xi2_{i-1}): 2 h dependent 12x12 mat-vecs if taken
+    //     step by step.  They are taken BLOCK-wise instead: per block b of S steps the affine map out = A_b in - c_b, whose
+    //     c_b is a recurrence over the block's own steps; all blocks form theirs at the same time, one per DPP row; a short
+    //     chain over the NB blocks gives every block's input; the blocks then replay their steps from it, again in parallel.
+    //     Dependent depth S + NB + S instead of h (h = 40: 18).  Every mat-vec is `row_matvec12`: one state coordinate per
+    //     lane of a DPP row, operands by row broadcast, no LDS round trip inside a chain.
     {
+      // (five steps per lane: the lane's coordinates pass through an opaque asm, or the address arithmetic of the six loops
+      //  below is hoisted out of the ITERATION loop, stays in registers across every other phase and spills; the smaller
+      //  variants have the registers and are 1.5 % faster with the hoisting)
+      int rn = rn_lane, wvq = wv, lq = l;
+      if constexpr (NP > 4) { BMPC_OPAQUE(rn); BMPC_OPAQUE(wvq); BMPC_OPAQUE(lq); }
+      const int BS = (H + 4 * NW - 1) / (4 * NW), NB = (H + BS - 1) / BS, sb = wvq * 4 + (lq >> 4);
       const int r6 = rn >= 6 ? rn - 6 : 0;      // component of bt / w the lane reads (0 for the lanes that read none)
-      const int d6 = rn >= 6 ? rn - 6 : 6;      // component of g / a the lane writes (6: the dump slot)
-      const float sel = rn >= 6 ? 1.f : 0.f;
-      // Four steps per trip: the operands of a step are requested two steps ahead, so that their LDS latency is
-      // covered by two chain steps (a single wave has nobody else to hide it); H is even, a last pair is handled alone.
-      float ca[12], cb[12], cc[12], cd[12], va, vb, vc, vd;
-      float p = 0.f;
-      auto load_col = [&](int k, float (&cf)[12], float& btv) {       // k-th step of the backward pass: i = H - 1 - k
-        const int i = H - 1 - (k < H ? k : H - 1);
+      const bool bok = sb < NB;
+      // r_i = M_i' [0; bt_i] = Kn_i' bt_i: per step, by the step's own lanes
 #pragma unroll
-        for (int m = 0; m < 12; ++m) cf[m] = sm.Mf[i][m][rn];
-        btv = sm.u.itv.bt[i][r6];
-      };
-      auto back_step = [&](int k, const float (&cf)[12], float btv) {
-        const int i = H - 1 - k;
-        const float uu = fmaf(-sel, btv, p);      // [p1; g = p2 - bt]
-        sm.u.itv.gs[i][d6] = uu;
-        p = row_matvec12(p, uu, cf);
-      };
-      int k = 0;
-      if (wv == 0) {                            // (wave-uniform: the sequential passes run on one wave)
-        load_col(0, ca, va);
-        load_col(1, cb, vb);
-#pragma unroll 1
-        for (; k + 4 <= H; k += 4) {
-          load_col(k + 2, cc, vc);
-          load_col(k + 3, cd, vd);
-          BMPC_SCHED_BARRIER();
-          back_step(k, ca, va);
-          back_step(k + 1, cb, vb);
-          load_col(k + 4, ca, va);
-          load_col(k + 5, cb, vb);
-          BMPC_SCHED_BARRIER();
-          back_step(k + 2, cc, vc);
-          back_step(k + 3, cd, vd);
+      for (int s = 0; s < NP; ++s) {
+        const int j = js[s];
+        float acc = 0.f;
+        if (sreal[s]) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) acc = fmaf(sm.Kn[j][m][n], sm.u.itv.bt[j][m], acc);
         }
-        if (k < H) { back_step(k, ca, va); back_step(k + 1, cb, vb); }
+        sm.u.itv.rbw[j][n] = acc;
+        BMPC_PASS_FENCE(s);
       }
-      BMPC_SSTAMP(6)                            // (diagnostics: the backward pass alone)
+      sync_all();
+      // two steps per trip; the coefficients AND the vector operands of the next step are requested before this step's
+      // mat-vec (LDS returns in order: a read issued inside a step would wait for the whole prefetch in front of it)
+      float ca[12], cb[12], va[2], vb[2];
+      // B2: c_b of the backward map: y <- F_i' y + r_i over the block's steps, last step first
+      auto loadB = [&](int t, float (&cf)[12], float (&v)[2]) __attribute__((always_inline)) {
+        const int i = sb * BS + t;               // (t < 0: the prefetch past the last step; loaded and dropped)
+        const bool ok = bok && i < H;
+        const int ic = i < 0 ? 0 : (i < H ? i : H - 1);
+        m_col(rn, ic, ok, cf);
+        const float* rp = ok ? &sm.u.itv.rbw[ic][rn] : &sm.zblk[0];
+        v[0] = *rp;
+        v[1] = sm.u.itv.bt[ic][r6];
+      };
+      {
+        float y = 0.f;
+        auto stepB = [&](const float (&cf)[12], const float (&v)[2]) __attribute__((always_inline)) {
+          y = row_matvec12(y + v[0], y, cf);
+        };
+        int t = BS - 1;
+        loadB(t, ca, va);
+#pragma unroll 1
+        for (; t >= 1; t -= 2) {
+          loadB(t - 1, cb, vb);
+          BMPC_SCHED_BARRIER();
+          stepB(ca, va);
+          loadB(t - 2, ca, va);
+          BMPC_SCHED_BARRIER();
+          stepB(cb, vb);
+        }
+        if (t == 0) stepB(ca, va);
+        sm.blkv[sb][rn] = y;
+      }
+      BMPC_SSTAMP(6)
+      sync_all();
+      // chain over the blocks, last block first: p_in(b) is stored, p <- A_b' p - c_b
+      if (wv == 0) {
+        float p = 0.f;
+        auto loadC = [&](int b, float (&cf)[12], float (&v)[2]) __attribute__((always_inline)) {
+          const int bc = b >= 0 ? b : 0;
+#pragma unroll
+          for (int m = 0; m < 12; ++m) cf[m] = sm.Ab[bc][m][rn];
+          v[0] = sm.blkv[bc][rn];
+        };
+        auto stepC = [&](int b, const float (&cf)[12], const float (&v)[2]) __attribute__((always_inline)) {
+          sm.blkp[b][rn] = p;
+          p = row_matvec12(-v[0], p, cf);     // (A_b is the full block map: the accumulator starts from -c_b alone)
+        };
+        int b = NB - 1;
+        loadC(b, ca, va);
+#pragma unroll 1
+        for (; b >= 1; b -= 2) {
+          loadC(b - 1, cb, vb);
+          BMPC_SCHED_BARRIER();
+          stepC(b, ca, va);
+          loadC(b - 2, ca, va);
+          BMPC_SCHED_BARRIER();
+          stepC(b - 1, cb, vb);
+        }
+        if (b == 0) stepC(0, ca, va);
+      }
+      sync_all();
+      // B3: replay of the blocks from their inputs: g_i = p2 - bt_i, then p <- F_i' p - r_i
+      {
+        float y = sm.blkp[bok ? sb : 0][rn];
+        y = bok ? y : 0.f;
+        auto stepR = [&](int t, const float (&cf)[12], const float (&v)[2]) __attribute__((always_inline)) {
+          const int i = sb * BS + t;
+          const bool ok = bok && i < H;
+          sm.u.itv.gs[ok ? i : 0][(ok && rn >= 6) ? rn - 6 : 6] = y - v[1];      // g_i (slot 6: dump)
+          y = row_matvec12(y - v[0], y, cf);
+        };
+        int t = BS - 1;
+        loadB(t, ca, va);
+#pragma unroll 1
+        for (; t >= 1; t -= 2) {
+          loadB(t - 1, cb, vb);
+          BMPC_SCHED_BARRIER();
+          stepR(t, ca, va);
+          loadB(t - 2, ca, va);
+          BMPC_SCHED_BARRIER();
+          stepR(t - 1, cb, vb);
+        }
+        if (t == 0) stepR(0, ca, va);
+      }
       sync_all();
       // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value); it replaces bt
 #pragma unroll
@@ -1094,43 +1231,93 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
         for (int m = 0; m < 6; ++m) acc = fmaf(sm.Sinv[j][c][m], sm.u.itv.gs[j][m], acc);
         sm.u.itv.bt[j][c] = acc;
+        BMPC_PASS_FENCE(s);
       }
       sync_all();
-      float x = 0.f;
-      auto load_row = [&](int k, float (&cf)[12], float& wvv) {
-        const int i = k < H ? k : H - 1;
-#pragma unroll
-        for (int m = 0; m < 12; m += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(&sm.Mf[i][rn][m]);
-          cf[m] = v.x; cf[m + 1] = v.y; cf[m + 2] = v.z; cf[m + 3] = v.w;
-        }
-        wvv = sm.u.itv.bt[i][r6];
+      // F2: c_b of the forward map: y <- F_i y + [0; w_i] over the block's steps, first step first
+      auto loadF = [&](int t, float (&cf)[12], float (&v)[2]) __attribute__((always_inline)) {
+        const int i = sb * BS + t;               // (t >= BS: the prefetch past the last step; loaded and dropped)
+        const bool ok = bok && i < H;
+        const int ic = i < H ? i : H - 1;
+        m_row(rn, ic, ok, cf);
+        const float* wp = (ok && rn >= 6) ? &sm.u.itv.bt[ic][rn - 6] : &sm.zblk[0];
+        v[0] = *wp;
       };
-      auto fwd_step = [&](int i, const float (&cf)[12], float wvv) {
-        // rows 0..5: (C xi2)[rn];  rows 6..11: the acceleration a_i[rn - 6] = -K xi - w
-        const float inc = row_matvec12(-sel * wvv, x, cf);
-        sm.u.itv.av[i][d6] = inc;
-        x += inc;
-        sm.u.itv.xi[i][rn] = x;
-      };
-      k = 0;
-      if (wv == 0) {
-        load_row(0, ca, va);
-        load_row(1, cb, vb);
+      {
+        float y = 0.f;
+        auto stepF = [&](const float (&cf)[12], const float (&v)[2]) __attribute__((always_inline)) {
+          y = row_matvec12(y + v[0], y, cf);
+        };
+        int t = 0;
+        loadF(0, ca, va);
 #pragma unroll 1
-        for (; k + 4 <= H; k += 4) {
-          load_row(k + 2, cc, vc);
-          load_row(k + 3, cd, vd);
+        for (; t + 2 <= BS; t += 2) {
+          loadF(t + 1, cb, vb);
           BMPC_SCHED_BARRIER();
-          fwd_step(k, ca, va);
-          fwd_step(k + 1, cb, vb);
-          load_row(k + 4, ca, va);
-          load_row(k + 5, cb, vb);
+          stepF(ca, va);
+          loadF(t + 2, ca, va);
           BMPC_SCHED_BARRIER();
-          fwd_step(k + 2, cc, vc);
-          fwd_step(k + 3, cd, vd);
+          stepF(cb, vb);
         }
-        if (k < H) { fwd_step(k, ca, va); fwd_step(k + 1, cb, vb); }
+        if (t < BS) stepF(ca, va);
+        sm.blkv[sb][rn] = y;
+      }
+      sync_all();
+      // chain over the blocks, first block first: xi_in(b) is stored, xi <- A_b xi - c_b
+      if (wv == 0) {
+        float x = 0.f;
+        auto loadC = [&](int b, float (&cf)[12], float (&v)[2]) __attribute__((always_inline)) {
+          const int bc = b < NB ? b : 0;
+#pragma unroll
+          for (int m = 0; m < 12; m += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(&sm.Ab[bc][rn][m]);
+            cf[m] = q.x; cf[m + 1] = q.y; cf[m + 2] = q.z; cf[m + 3] = q.w;
+          }
+          v[0] = sm.blkv[bc][rn];
+        };
+        auto stepC = [&](int b, const float (&cf)[12], const float (&v)[2]) __attribute__((always_inline)) {
+          sm.blkp[b][rn] = x;
+          x = row_matvec12(-v[0], x, cf);
+        };
+        int b = 0;
+        loadC(0, ca, va);
+#pragma unroll 1
+        for (; b + 2 <= NB; b += 2) {
+          loadC(b + 1, cb, vb);
+          BMPC_SCHED_BARRIER();
+          stepC(b, ca, va);
+          loadC(b + 2, ca, va);
+          BMPC_SCHED_BARRIER();
+          stepC(b + 1, cb, vb);
+        }
+        if (b < NB) stepC(b, ca, va);
+      }
+      sync_all();
+      // F3: replay: xi_i = F_i xi_{i-1} - [0; w_i]; the acceleration is the increment of the (w, v) half
+      {
+        float y = sm.blkp[bok ? sb : 0][rn];
+        y = bok ? y : 0.f;
+        auto stepP = [&](int t, const float (&cf)[12], const float (&v)[2]) __attribute__((always_inline)) {
+          const int i = sb * BS + t;
+          const bool ok = bok && i < H;
+          const int ic = ok ? i : 0;
+          const float yn = row_matvec12(y - v[0], y, cf);
+          sm.u.itv.av[ic][(ok && rn >= 6) ? rn - 6 : 6] = yn - y;
+          if (ok) sm.u.itv.xi[ic][rn] = yn;
+          y = yn;
+        };
+        int t = 0;
+        loadF(0, ca, va);
+#pragma unroll 1
+        for (; t + 2 <= BS; t += 2) {
+          loadF(t + 1, cb, vb);
+          BMPC_SCHED_BARRIER();
+          stepP(t, ca, va);
+          loadF(t + 2, ca, va);
+          BMPC_SCHED_BARRIER();
+          stepP(t + 1, cb, vb);
+        }
+        if (t < BS) stepP(t, ca, va);
       }
     }
     sync_all();
