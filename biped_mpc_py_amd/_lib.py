@@ -8,11 +8,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
-    "bmpc_abi_version", "bmpc_last_error", "bmpc_supported_horizon", "bmpc_supported_horizon_path", "bmpc_solver_path",
+    "bmpc_abi_version", "bmpc_last_error", "bmpc_supported_horizon", "bmpc_supported_horizon_path", "bmpc_solver_path", "bmpc_rescue_enabled",
     "bmpc_effective_penalties",
     "bmpc_default_params",
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
@@ -51,7 +51,7 @@ class CParams(C.Structure):
         ("eps_pri", C.c_double), ("eps_dua", C.c_double),
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
         ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("warm_adapt_start", C.c_int32),
-        ("path", C.c_int32), ("penalty_mode", C.c_int32),
+        ("path", C.c_int32), ("penalty_mode", C.c_int32), ("rescue", C.c_int32),
         ("kp", C.c_double * 9), ("kd", C.c_double * 9), ("swingHeight", C.c_double), ("hip_offset", C.c_double * 3),
     ]
 
@@ -96,6 +96,8 @@ def load():
     lib.bmpc_supported_horizon.argtypes = [ip]
     lib.bmpc_supported_horizon_path.argtypes = [ip, ip]
     lib.bmpc_solver_path.argtypes = [vp]
+    lib.bmpc_rescue_enabled.argtypes = [vp]
+    lib.bmpc_rescue_enabled.restype = ip
     lib.bmpc_effective_penalties.argtypes = [C.POINTER(CParams), C.POINTER(C.c_double)]
     lib.bmpc_default_params.argtypes = [C.POINTER(CParams), ip]
     lib.bmpc_create.argtypes = [C.POINTER(vp), C.POINTER(CParams), ip, ip]

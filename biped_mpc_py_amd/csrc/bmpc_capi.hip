@@ -83,6 +83,22 @@ CurvScales curvature_scales(const bmpc_params& p) {
   return c;
 }
 
+// Is a dense solve followed by the rescue pass?  BMPC_RESCUE_AUTO: only away from the reference's model and weights
+// (REF:22-48) -- there the dense family has converged on every one of 6 M soaked instances and the extra launch would
+// cost the headline configuration ~1 % for nothing; at other weights 1 instance in 10^3..10^4 can stall.
+bool resolve_rescue(const bmpc_params& p) {
+  if (resolve_path(p.h, p.path) != BMPC_PATH_DENSE || !stage_horizon(p.h) || p.rescue == BMPC_RESCUE_OFF) return false;
+  if (p.rescue == BMPC_RESCUE_ON) return true;
+  bmpc_params ref;
+  bmpc_default_params(&ref, p.h);
+  bool same = p.dt == ref.dt && p.m == ref.m && p.g == ref.g && p.lt == ref.lt && p.lh == ref.lh;
+  for (int i = 0; i < 12; ++i) same = same && p.Q[i] == ref.Q[i] && p.R[i] == ref.R[i];
+  for (int i = 0; i < 9; ++i) same = same && p.I[i] == ref.I[i];
+  for (int i = 0; i < 3; ++i)
+    same = same && p.f_max[i] == ref.f_max[i] && p.f_min[i] == ref.f_min[i] && p.tau_max[i] == ref.tau_max[i] && p.tau_min[i] == ref.tau_min[i];
+  return !same;
+}
+
 int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   if (!resolve_path(p.h, p.path)) return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d for path %d", p.h, p.path);
   if (p.half < 1) return fail(BMPC_ERR_INVALID, "half must be >= 1");
@@ -91,6 +107,7 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     return fail(BMPC_ERR_INVALID, "penalties must be positive");
   if (!(p.kappa > 1)) return fail(BMPC_ERR_INVALID, "kappa must be > 1");
   if (p.max_iter < 1 || p.check_every < 1) return fail(BMPC_ERR_INVALID, "max_iter, check_every must be >= 1");
+  if (p.rescue < BMPC_RESCUE_AUTO || p.rescue > BMPC_RESCUE_ON) return fail(BMPC_ERR_INVALID, "unknown rescue mode %d", p.rescue);
   std::memset(d, 0, sizeof(*d));
   d->h = p.h; d->half = p.half; d->max_iter = p.max_iter; d->check_every = p.check_every;
   d->adapt_start = p.adapt_start; d->adapt_every = p.adapt_every; d->max_refactor = p.max_refactor;
@@ -176,6 +193,7 @@ struct bmpc_handle_s {
   bmpc_params params;
   bmpc::DevParams dev;
   int path = BMPC_PATH_DENSE;      // resolved kernel family (resolve_path)
+  bool rescue_on = false;          // dense solves are followed by the stage family's rescue pass (resolve_rescue)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -215,7 +233,7 @@ int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const 
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
              hipStream_t st, const int32_t* order) {
   constexpr int NT = bmpc::Dims<H>::NT;
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order};
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order, nullptr};
   if (hd->warm_on && !dbg.assemble_only) {
     const size_t need = (size_t)B * NT * 6;
     if (need > hd->warm.n) hd->warm_valid = false;          // growing the buffer loses the stored state
@@ -242,9 +260,9 @@ template <int NP, int NW>
 int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                  const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
                  int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-                 hipStream_t st, const int32_t* order) {
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order};
-  if (hd->warm_on && !dbg.assemble_only) {
+                 hipStream_t st, const int32_t* order, const int32_t* rescue_status = nullptr) {
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order, rescue_status};
+  if (hd->warm_on && !dbg.assemble_only && !rescue_status) {   // (a rescue pass starts cold: the stored state is the dense family's)
     const size_t need = (size_t)B * (5 * NP * NW) * 12 * 6;  // [B][5 NP NW][12][6] doubles
     if (need > hd->warm.n) hd->warm_valid = false;
     HIP_TRY(hd->warm.ensure(need));
@@ -266,6 +284,19 @@ int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, co
   return BMPC_OK;
 }
 
+int launch_stage_any(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                     const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+                     int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
+                     hipStream_t st, const int32_t* order, const int32_t* rescue_status) {
+  // compiled per (steps a lane owns, waves per instance): bmpc::stage_steps_per_lane / stage_waves
+  switch (10 * bmpc::stage_waves(hd->dev.h) + bmpc::stage_steps_per_lane(hd->dev.h)) {
+#define BMPC_CASE(NN, WW) case 10 * WW + NN: return launch_stage<NN, WW>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order, rescue_status);
+    BMPC_CASE(2, 1) BMPC_CASE(3, 1) BMPC_CASE(4, 1) BMPC_CASE(5, 1) BMPC_CASE(3, 2) BMPC_CASE(4, 2)
+#undef BMPC_CASE
+    default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
+  }
+}
+
 int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
            const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
            int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
@@ -273,20 +304,30 @@ int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const ui
   const bool dense_views = dbg.assemble_only && (dbg.Gt || dbg.qt);      // Gt, qt only exist on the dense path
   if (hd->path == BMPC_PATH_STAGE && !(dense_views && dense_horizon(hd->dev.h))) {
     if (dense_views) return fail(BMPC_ERR_INVALID, "Gt / qt views exist for h <= 20 only (h=%d never forms them)", hd->dev.h);
-    // compiled per (steps a lane owns, waves per instance): bmpc::stage_steps_per_lane / stage_waves
-    switch (10 * bmpc::stage_waves(hd->dev.h) + bmpc::stage_steps_per_lane(hd->dev.h)) {
-#define BMPC_CASE(NN, WW) case 10 * WW + NN: return launch_stage<NN, WW>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order);
-      BMPC_CASE(2, 1) BMPC_CASE(3, 1) BMPC_CASE(4, 1) BMPC_CASE(5, 1) BMPC_CASE(3, 2) BMPC_CASE(4, 2)
-#undef BMPC_CASE
-      default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
-    }
+    return launch_stage_any(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st,
+                            order, nullptr);
   }
+  // Dense family.  With the rescue pass on, the instances whose status is not 0 afterwards are solved again by the
+  // stage-structured kernel of the same horizon (f32 Riccati recursion instead of the f32 explicit inverse: it does not
+  // share the dense sweep's rare breakdowns; profiles/r03_soak.txt): one more launch whose workgroups leave at once
+  // where the status is 0, no host round trip.
+  const bool rescue = hd->rescue_on && !dbg.assemble_only;
+  if (rescue && !status) {
+    HIP_TRY(hd->status.ensure((size_t)B));
+    status = hd->status.p;
+  }
+  int rc = BMPC_ERR_INVALID;
   switch (hd->dev.h) {
-#define BMPC_CASE(HH) case HH: return launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order);
+#define BMPC_CASE(HH) case HH: rc = launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order); break;
     BMPC_DENSE_HORIZONS(BMPC_CASE)
 #undef BMPC_CASE
     default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
   }
+  if (rc != BMPC_OK || !rescue) return rc;
+  bmpc::DebugOut quiet = dbg;
+  quiet.prof = nullptr;                        // the cycle stamps stay those of the first solve
+  return launch_stage_any(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, quiet, st,
+                          order, status);
 }
 
 // NULL is HIP's null (legacy default) stream, like every hip* call; BMPC_STREAM_OWN the handle's own stream
@@ -330,6 +371,11 @@ int bmpc_solver_path(bmpc_handle h) {
   return h->path;
 }
 
+int bmpc_rescue_enabled(bmpc_handle h) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  return h->rescue_on ? 1 : 0;
+}
+
 int bmpc_default_params(bmpc_params* p, int h) {
   if (!p) return fail(BMPC_ERR_INVALID, "null params");
   std::memset(p, 0, sizeof(*p));
@@ -365,6 +411,7 @@ int bmpc_default_params(bmpc_params* p, int h) {
   //  period 10 again; measured with tools/stage_probe.py)
   p->adapt_every = (h <= 12 || h > 20) ? 10 : 20;
   p->adapt_start = (h < 20 || h > 20) ? 10 : 20;
+  p->rescue = BMPC_RESCUE_AUTO;
   p->warm_adapt_start = 5;                                            // (tools/warm_sweep.py)
   p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
   p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31
@@ -388,6 +435,7 @@ int bmpc_create(bmpc_handle* out, const bmpc_params* params, int device, int max
   if (!h) return fail(BMPC_ERR_ALLOC, "out of host memory");
   h->device = device; h->max_batch = max_batch; h->params = *params; h->dev = dev;
   h->path = resolve_path(params->h, params->path);
+  h->rescue_on = resolve_rescue(*params);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -427,6 +475,7 @@ int bmpc_set_params(bmpc_handle h, const bmpc_params* params) {
   if (resolve_path(params->h, params->path) != h->path) h->warm_valid = false;   // the two families keep different state
   h->params = *params; h->dev = dev;
   h->path = resolve_path(params->h, params->path);
+  h->rescue_on = resolve_rescue(*params);
   return BMPC_OK;
 }
 

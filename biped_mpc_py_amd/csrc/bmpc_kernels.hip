@@ -116,6 +116,9 @@ struct WarmArgs {
   // dispatch order or null: workgroup g solves instance order[g] (a permutation of 0 .. B-1).  Workgroups start in
   // index order, so listing the instances expected to take longest first keeps the tail of a batch short.
   const int32_t* order;
+  // rescue pass or null (stage-structured kernels only): a status array of an earlier solve of the same batch; the
+  // instances it reports solved (0) are left alone, the others are solved again from a cold start
+  const int32_t* rescue_status;
 };
 
 template <int H>

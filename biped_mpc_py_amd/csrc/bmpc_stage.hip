@@ -198,6 +198,7 @@ stage_body(const DevParams& P, const int B,
 
   if ((int)blockIdx.x >= B) return;
   const int inst = warm.order ? warm.order[blockIdx.x] : (int)blockIdx.x;
+  if (warm.rescue_status && warm.rescue_status[inst] == 0) return;     // (workgroup uniform, before any barrier)
   const int H = P.h;                           // NP = ceil(H / 5) (checked on the host)
 #ifdef BMPC_EMU
   if (threadIdx.x == 0) std::memset(&sm, g_poison, sizeof(sm));

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 6
+#define BMPC_ABI_VERSION 7
 
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
@@ -48,6 +48,13 @@ enum bmpc_path {
 enum bmpc_penalty_mode {
   BMPC_PENALTY_SCALED = 0,
   BMPC_PENALTY_ABSOLUTE = 1
+};
+
+/* bmpc_params.rescue */
+enum bmpc_rescue_mode {
+  BMPC_RESCUE_AUTO = -1,
+  BMPC_RESCUE_OFF = 0,
+  BMPC_RESCUE_ON = 1
 };
 
 /* per-instance status[] values written by the solver */
@@ -105,6 +112,12 @@ typedef struct bmpc_params {
                                 problem (REF:22-48 defaults, h = 10) and are scaled by the curvature of the problem at
                                 hand relative to it -- stiff end (Q, dt, m, I, h) for the ceilings and rho_eq, 2 R for the
                                 floor, their geometric mean for the start; BMPC_PENALTY_ABSOLUTE: taken as they are */
+  int32_t rescue;            /* BMPC_RESCUE_AUTO (default), _OFF, _ON: after a solve on the dense family, the instances whose
+                                status is not 0 are solved again by the stage family (one more launch on the same stream,
+                                its workgroups leave at once where the status is 0; the outputs of a rescued instance,
+                                iters / nfactor / residuals included, are those of the second solve).  AUTO: on unless the
+                                model and weights are the reference's own (REF:22-48), where the dense family has not
+                                lost an instance in 6 M and the launch would only cost ~1 %.  No effect on the stage path. */
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
   double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
   double swingHeight;        /* REF:32 */
@@ -125,6 +138,8 @@ int bmpc_supported_horizon_path(int h, int path);
 int bmpc_effective_penalties(const bmpc_params* params, double* out5);
 /* The kernel family a handle's solves run on (BMPC_PATH_DENSE or BMPC_PATH_STAGE; <0 on error). */
 int bmpc_solver_path(bmpc_handle h);
+/* 1 if this handle's solves are followed by the rescue pass (see bmpc_params.rescue), else 0 (<0 on error). */
+int bmpc_rescue_enabled(bmpc_handle h);
 /* Reference defaults (REF:22-48) and solver defaults for horizon h. */
 int bmpc_default_params(bmpc_params* p, int h);
 

@@ -978,3 +978,55 @@ def test_parity_against_the_oracle_at_scale():
             util.rel_err(u[7074][None], ref[7074][None])[0]))
         assert (info["status"] == 0).all()
         assert e.max() <= (5e-5 if path == PATH_DENSE else 5e-6)
+
+
+def test_rescue_pass_recovers_what_the_dense_sweep_loses():
+    """bmpc_params.rescue: away from the reference's weights the dense family's f32 explicit inverse stalls on about one
+    instance in 10^3..10^4 (Q x 10, standing: 5 of 16384).  With the rescue pass (default there) those instances are
+    solved again by the stage family on the same stream: every status is 0, the rescued controls are the oracle's
+    (<= 1e-4), every other instance is bit-identical to the run without it, and at the reference's own weights AUTO
+    leaves the pass off."""
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd.params import RESCUE_AUTO, RESCUE_OFF, RESCUE_ON
+    B, h = 16384, 10
+    s = util.synth_batch(B, h, 77 + h, gait="standing")
+    mod = lambda m: setattr(m, "Q", np.asarray(m.Q, float) * 10.0)
+    out = {}
+    for mode in (RESCUE_OFF, RESCUE_AUTO, RESCUE_ON):
+        mpc = bm.MPC()
+        mod(mpc)
+        sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(rescue=mode))
+        assert sol._lib.bmpc_solver_path(sol._h) == PATH_DENSE
+        assert sol._lib.bmpc_rescue_enabled(sol._h) == (0 if mode == RESCUE_OFF else 1)
+        _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], want_states=False)
+        out[mode] = (u, info)
+        sol.close()
+    lost = np.nonzero(out[RESCUE_OFF][1]["status"])[0]
+    print("dense path alone: %d of %d not converged %s" % (len(lost), B, lost[:10]))
+    for mode in (RESCUE_AUTO, RESCUE_ON):
+        u, info = out[mode]
+        assert int((info["status"] != 0).sum()) == 0
+        keep = np.setdiff1d(np.arange(B), lost)
+        assert np.array_equal(u[keep], out[RESCUE_OFF][0][keep])
+        assert np.array_equal(info["iters"][keep], out[RESCUE_OFF][1]["iters"][keep])
+    if len(lost):
+        idx = lost[:6]
+        ref = _oracle_controls(s, idx, h, mod, None)
+        rel = util.rel_err(out[RESCUE_ON][0][idx], ref)
+        print("rescued instances: err max %.2e" % rel.max())
+        assert rel.max() <= util.REL_TOL
+    # the reference's own model and weights: AUTO leaves it off (nothing to rescue in 6 M soaked instances), ON still works
+    for mode, want in ((RESCUE_AUTO, 0), (RESCUE_ON, 1)):
+        sol = bm.BatchSolver(mpc=bm.MPC(), half=s["half"], max_batch=256, solver_options=dict(rescue=mode))
+        assert sol._lib.bmpc_rescue_enabled(sol._h) == want
+        _, u2, i2 = sol.solve(s["x_fb"][:256], s["foot"][:256], s["contact"][:256], s["phase"][:256], want_states=False)
+        assert int((i2["status"] != 0).sum()) == 0
+        out[("ref", mode)] = u2
+        sol.close()
+    assert np.array_equal(out[("ref", RESCUE_AUTO)], out[("ref", RESCUE_ON)])
+    # no rescue on the stage path itself
+    mpc = bm.MPC()
+    mod(mpc)
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=8, solver_options=dict(path=PATH_STAGE, rescue=RESCUE_ON))
+    assert sol._lib.bmpc_rescue_enabled(sol._h) == 0
+    sol.close()

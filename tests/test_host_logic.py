@@ -150,3 +150,21 @@ def test_solver_defaults_follow_the_horizon():
         assert cp.check_every == 5 and cp.warm_adapt_start == 5 and cp.kappa == 20.0
     cp = bm.pack_params(bm.MPC(), bm.Biped(), solver_options=dict(adapt_every=15, rho=0.02))      # overrides still apply
     assert cp.adapt_every == 15 and cp.rho == 0.02
+
+
+def test_rescue_mode_is_a_solver_option_with_default_auto():
+    """bmpc_params.rescue (include/bmpc.h enum bmpc_rescue_mode): AUTO by default, settable through solver_options, and an
+    unknown mode is refused by the library's parameter check (host arithmetic, no device)."""
+    import ctypes as C
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import _lib
+    from biped_mpc_py_amd.params import RESCUE_AUTO, RESCUE_OFF, RESCUE_ON
+    assert (RESCUE_AUTO, RESCUE_OFF, RESCUE_ON) == (-1, 0, 1)
+    cp = bm.pack_params(bm.MPC(), bm.Biped())
+    assert cp.rescue == RESCUE_AUTO
+    assert bm.pack_params(bm.MPC(), bm.Biped(), solver_options=dict(rescue=RESCUE_ON)).rescue == RESCUE_ON
+    out = (C.c_double * 5)()
+    assert _lib.load().bmpc_effective_penalties(C.byref(cp), out) == 0
+    cp.rescue = 3
+    assert _lib.load().bmpc_effective_penalties(C.byref(cp), out) != 0
+    assert b"rescue" in _lib.load().bmpc_last_error()
