@@ -147,6 +147,13 @@ def flops_run(h, iters, nfactor):
     return f_setup + nfactor * f_factor + iters * f_iter, dict(setup=f_setup, factor=f_factor, iteration=f_iter)
 
 
+def stage_variant(h):
+    """(steps a lane owns, waves per instance) of the stage-structured kernel that serves horizon h
+    (bmpc_stage.hip: stage_steps_per_lane / stage_waves): one wave up to h = 24, two from h = 26."""
+    nw = 1 if h <= 24 else 2
+    return -(-h // (5 * nw)), nw
+
+
 def flops_run_stage(h, iters, nfactor):
     """Flops of the stage-structured path (bmpc_stage.hip; 1 MAC = 2 flops): O(h) everywhere.  Set-up: references, step
     data, free response (~400 per step).  Per factorisation: the 6x6 block algebra (as the dense path, 7000 per step)
@@ -523,7 +530,7 @@ def run_rank(args):
                          "achieved_survey_formula": ach_s, "frac_survey_formula": ach_s / PEAK_FP32_TFLOPS,
                          "mfma_util": 0.0, "mfma_ops_counter": mfma_ops,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_sha": ksha,
-                         "kernel": (f"bmpc::solve_kernel<{h}>" if path_used == "dense" else f"bmpc::stage_kernel<{(h + 4) // 5}>"),
+                         "kernel": (f"bmpc::solve_kernel<{h}>" if path_used == "dense" else f"bmpc::stage_kernel<{stage_variant(h)[0]}, {stage_variant(h)[1]}>"),
                          "kernel_ms": kernel_ms,
                          "flops_per_solve": fl_r, "flops_parts": parts, "flops_per_solve_survey_formula": fl_s,
                          "note": "`achieved` / `frac`: the flops of the algorithm that runs (symmetric work counted once) over "

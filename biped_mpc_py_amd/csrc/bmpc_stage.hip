@@ -21,15 +21,19 @@
 // coordinate n = 2 c + f -- at the NP consecutive steps j = (q NW + w) NP + s (s = 0 .. NP-1).  The 12 lanes of a step
 // always sit in one wave, so what they exchange stays wave-local; with two waves only the scans over the steps, the
 // two sequential passes and the Riccati recursion (run by wave 0) and the reductions cross a workgroup barrier.
-// (Two waves halve the steps a lane owns: at h = 40 one wave would need ~1000 registers and spill half of them.)  Steps past the horizon are PHANTOMS: they have their own LDS slots (the step
-// arrays hold 5 NP steps), read the inputs of step h - 1, do the same arithmetic as everybody else and are masked out
-// of everything that crosses steps (scans, the sequential passes, reductions, outputs) -- nothing is predicated on
-// them.  h is a launch parameter: the kernel is compiled per NP = ceil(h / 5) (NP = 2 .. 8: h = 8 .. 40).
+// (Two waves halve the steps a lane owns: at h = 40 one wave would need ~1000 registers and spill half of them.)
+// Steps past the horizon are PHANTOMS: they have their own LDS slots (the step arrays hold 5 NP NW steps), read the
+// inputs of step h - 1, do the same arithmetic as everybody else and are masked out of everything that crosses steps
+// (scans, the sequential passes, reductions, outputs) -- nothing is predicated on them.  h is a launch parameter: the
+// kernel is compiled per (NP, NW) = (steps a lane owns, waves): (2,1) h <= 10 ... (5,1) h <= 24, (3,2) h <= 30, (4,2) h <= 40.
 // Within a wave no s_barrier: lanes of one wave exchange through LDS in program order (BMPC_WAVE_SYNC only fences the
 // compiler) and through DPP.  The two sequential passes of a solve run on the 12 lanes of a DPP row, one state
-// coordinate per lane, as 12x12 mat-vecs whose operands arrive by row broadcast (no LDS round trip in the chain).
-// An instance needs no register-resident matrix, so many instances share a CU: the path is bound by the latency of
-// its dependent chains, and throughput comes from the number of instances in flight.
+// coordinate per lane, as 12x12 mat-vecs whose operands arrive by row broadcast (no LDS round trip in a chain) -- and
+// BLOCK-wise: the steps are grouped into NB <= 4 NW blocks of S steps, one block per DPP row; every row forms the affine
+// map of its block at the same time, a short chain over the blocks (their products A_b are part of the factorisation)
+// gives each block its input, and the rows replay their steps from it: S + NB + S dependent mat-vecs per pass instead
+// of h.  An instance needs no register-resident matrix, so many instances share a CU: the path is bound by the latency
+// of its dependent chains, and throughput comes from the number of instances in flight.
 
 #ifndef BMPC_EMU
 #include <hip/hip_runtime.h>

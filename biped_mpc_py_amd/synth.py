@@ -54,13 +54,19 @@ CONFIGS = {
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) over the kernel sources: stamps measurements that are replayed later
+    """sha256 (first 16 hex digits) over the CODE of the kernel sources -- comments and white space stripped, so that
+    editing the commentary does not orphan a measurement: stamps measurements that are replayed later
     (profiles/pmc_summary.json -> bench.py roofline.traffic), so that a figure taken with other kernels is refused."""
     import hashlib
     import os
+    import re
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     hsh = hashlib.sha256()
     for name in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip"):
-        with open(os.path.join(here, name), "rb") as fh:
-            hsh.update(fh.read())
+        with open(os.path.join(here, name), "r", encoding="utf-8") as fh:
+            text = fh.read()
+        # (no string literal of these files holds "//" or "/*": checked by tests/test_host_logic.py)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        hsh.update(" ".join(text.split()).encode())
     return hsh.hexdigest()[:16]

@@ -1,4 +1,6 @@
 """CPU: host-side logic of the drop-in (phase arithmetic, gait table, parameter packing, sharding maths)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -168,3 +170,16 @@ def test_rescue_mode_is_a_solver_option_with_default_auto():
     cp.rescue = 3
     assert _lib.load().bmpc_effective_penalties(C.byref(cp), out) != 0
     assert b"rescue" in _lib.load().bmpc_last_error()
+
+
+def test_kernel_source_hash_covers_code_not_commentary():
+    """synth.kernel_source_hash strips comments before hashing; that is only sound while no string literal of the kernel
+    sources contains a comment opener."""
+    import re
+    from biped_mpc_py_amd.synth import kernel_source_hash
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "biped_mpc_py_amd", "csrc")
+    for name in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip"):
+        text = open(os.path.join(here, name), encoding="utf-8").read()
+        for m in re.finditer(r'"([^"\n]*)"', text):
+            assert "//" not in m.group(1) and "/*" not in m.group(1), (name, m.group(0))
+    assert re.fullmatch(r"[0-9a-f]{16}", kernel_source_hash())
