@@ -87,10 +87,43 @@ __device__ __forceinline__ float row_matvec12(float acc, float u, const float (&
 #endif
 }
 
+// A per-step LDS array, stored with the step index PERMUTED: a lane group owns G = NP NW consecutive steps, so in one
+// LDS instruction the five groups of a wave touch steps G apart -- and with row sizes of 6 .. 72 words G rows are a
+// multiple of 32 banks for most arrays: 3- to 5-way conflicts (41 % of the LDS-array cycles at h = 40).  Step j lives
+// in slot (j mod G) 5 + j / G: the groups' rows become neighbours, the rows of one lane 5 slots apart.  Call sites index
+// by the step; only the storage order changes (no padding: the long-horizon variants have no LDS to spare).
+// a step together with its slot: the steps a lane owns sit at slot0 + 5 s, constant offsets from one base address
+struct Step {
+  int j, slot;
+  __device__ __forceinline__ operator int() const { return j; }
+};
+
+template <class Row, int HS, int G>
+struct StepArr {
+  Row v[HS];
+  // (G = 0: plain order -- the five-steps-per-lane variant has no registers for a second family of base addresses)
+  static __device__ __forceinline__ int slot_of(int j) { return G ? (int)(((unsigned)j % (unsigned)(G ? G : 1)) * 5u + (unsigned)j / (unsigned)(G ? G : 1)) : j; }
+  __device__ __forceinline__ Row& operator[](Step st) { return v[G ? st.slot : st.j]; }
+  __device__ __forceinline__ const Row& operator[](Step st) const { return v[G ? st.slot : st.j]; }
+  __device__ __forceinline__ Row& operator[](int j) { return v[slot_of(j)]; }
+  __device__ __forceinline__ const Row& operator[](int j) const { return v[slot_of(j)]; }
+};
+
+// the arrays the sequential parts walk step by step (Riccati recursion, the chains of a solve) keep the plain order:
+// there one instruction touches one step per DPP row or one step at all, and the permutation would only cost its
+// index arithmetic (measured: +5 % on the recursion, +8 % on the chains)
+template <class Row, int HS>
+struct PlainArr {
+  Row v[HS];
+  __device__ __forceinline__ Row& operator[](int j) { return v[j]; }
+  __device__ __forceinline__ const Row& operator[](int j) const { return v[j]; }
+};
+
 template <int NP, int NW>
 struct alignas(16) StageSmem {
   static constexpr int HS = 5 * NP * NW;       // step capacity
-  struct FootBlock { float d[HS][6][6]; };
+  static constexpr int G = NP <= 4 ? NP * NW : 0;   // consecutive steps of a lane group (0: per-step arrays in plain order)
+  struct FootBlock { StepArr<float[6][6], HS, G> d; };
   // f64 6x6 scratch of the block algebra of ONE pass (5 steps), indexed by lane group
   struct Fac {
     double M0[5 * NW][6][6];   // D0 -> Ka^-1 D0 W_0^-1
@@ -100,14 +133,14 @@ struct alignas(16) StageSmem {
   };
   // exchange vectors of an iteration; never live together with the factor scratch
   struct Itv {
-    RT wg[HS][2][6];           // y + rho (A x - z) on the general rows; x itself for the exact rebuild and the outputs
-    RT lam[HS][12];            // adjoint of the tracking error (acceleration space), and the scans' exchange
-    alignas(16) float r32[HS][2][6];   // KKT residual, control space; after P3 the step d of x
-    alignas(16) float bt[HS][6];       // right-hand side of the stage solve (E^-T beta); after the backward pass w = Sinv g
-    float gs[HS][8];           // g = p2 - bt of the backward pass (slot 6: dump for the lanes that hold no g)
-    float av[HS][8];           // accelerations a = E gamma of the solve (slot 6: dump)
-    alignas(16) float xi[HS][12];      // state response Gam_t gamma
-    alignas(16) float rbw[HS][12];     // backward pass: r_i = M_i' [0; bt_i]
+    StepArr<RT[2][6], HS, G> wg;           // y + rho (A x - z) on the general rows; x itself for the exact rebuild and the outputs
+    StepArr<RT[12], HS, G> lam;            // adjoint of the tracking error (acceleration space), and the scans' exchange
+    alignas(16) StepArr<float[2][6], HS, G> r32;   // KKT residual, control space; after P3 the step d of x
+    alignas(16) PlainArr<float[6], HS> bt;       // right-hand side of the stage solve (E^-T beta); after the backward pass w = Sinv g
+    PlainArr<float[8], HS> gs;           // g = p2 - bt of the backward pass (slot 6: dump for the lanes that hold no g)
+    PlainArr<float[8], HS> av;           // accelerations a = E gamma of the solve (slot 6: dump)
+    alignas(16) PlainArr<float[12], HS> xi;      // state response Gam_t gamma
+    alignas(16) PlainArr<float[12], HS> rbw;     // backward pass: r_i = M_i' [0; bt_i]
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
@@ -122,24 +155,24 @@ struct alignas(16) StageSmem {
   // algebra), C_i = dt blkdiag(Rinv_i, I) as its 3x3 block Cr_i.  The steps are grouped into NB <= 4 NW blocks of S
   // consecutive steps, one per DPP row of the instance, with the block products A_b = F_{last} .. F_{first}.
   static constexpr int NBM = 4 * NW;
-  alignas(16) float Kn[HS][6][12];
-  alignas(16) float Cr[HS][12];
+  alignas(16) PlainArr<float[6][12], HS> Kn;
+  alignas(16) PlainArr<float[12], HS> Cr;
   alignas(16) float Ab[NBM][12][12];
   alignas(16) float blkv[NBM][12];    // per block: the affine part of the block map
   alignas(16) float blkp[NBM][12];    // per block: the state entering it
   alignas(16) float zblk[72];         // zeros (coefficients of steps past the horizon)
   alignas(16) float dtrow[3][12];     // rows 3..5 of M_i (the same for every step): dt in column 9 + k
-  alignas(16) float Sinv[HS][6][6];
+  alignas(16) PlainArr<float[6][6], HS> Sinv;
   alignas(16) float Pm[12][12];   // Riccati recursion: cost-to-go
   alignas(16) float Zm[12][12];   //                    Schur complement (blocks 12, 22; Z11 replaces Pi11 in Pm)
   alignas(16) float Tm[6][6];     //                    S^-1 Ft
   float q2[12];                   // 2 Q
   // step data
-  RT Iwi[HS][9];               // world inverse inertia
-  RT Rv[HS][9];                // R_inv (REF:160-164)
-  RT rr[HS][2][3];             // r_f = foot_ref - com_ref
-  float muf[HS][2];
-  float rvg[HS][2][6];
+  StepArr<RT[9], HS, G> Iwi;               // world inverse inertia
+  StepArr<RT[9], HS, G> Rv;                // R_inv (REF:160-164)
+  StepArr<RT[2][3], HS, G> rr;             // r_f = foot_ref - com_ref
+  StepArr<float[2], HS, G> muf;
+  StepArr<float[2][6], HS, G> rvg;
   RT Gu[6][6];
   RT GuT[6][6];
   float eyz[6];
@@ -242,6 +275,9 @@ stage_body(const DevParams& P, const int B,
     sreal[s] = js[s] < H;
     jg[s] = js[s] < H ? js[s] : H - 1;          // index into the per-step inputs in HBM
   }
+  // step s of this lane with its LDS slot: StepArr's permutation of js[s] spelled out, one base + 5 s
+  const int slot0 = wv * NP * 5 + q;
+#define BMPC_STEP(s) (Step{js[s], slot0 + 5 * (s)})
 
   // (every lambda below is forced inline: one that is called from two places -- the scans, the exact rebuild -- is
   //  otherwise a real function inside a large module, and whatever it captures by reference then lives in scratch)
@@ -307,7 +343,7 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       const int j = jg[s];
-      const int jst = js[s];
+      const Step jst = BMPC_STEP(s);
       RT xr[12];                               // x_ref[:, j]  (REF:61-70)
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
@@ -378,7 +414,7 @@ stage_body(const DevParams& P, const int B,
   prefix_incl(err);
 #pragma unroll
   for (int s = 0; s < NP; ++s) {
-    const int j = js[s];
+    const Step j = BMPC_STEP(s);
     const RT j1 = (RT)(jg[s] + 1);
     RT e = xfb_n + err[s];                     // (err is zero for n >= 3)
     if (n >= 3 && n < 6) e += dt * j1 * (n == 3 ? xfb[9] : (n == 4 ? xfb[10] : xfb[11]));
@@ -425,7 +461,7 @@ stage_body(const DevParams& P, const int B,
     const int a = c < 3 ? c : c - 3;
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       const float cont = (float)contact[((size_t)inst * H + jg[s]) * 2 + f];
       const float muf = mu_in ? mu_in[((size_t)inst * H + jg[s]) * 2 + f] : (float)P.mu;
       if (c == 0) sm.muf[j][f] = muf;
@@ -486,7 +522,7 @@ stage_body(const DevParams& P, const int B,
   auto factor = [&]() __attribute__((always_inline)) {
     if constexpr (PROF) t_mark = clock64();
 #pragma unroll
-    for (int s = 0; s < NP; ++s) sm.rvg[js[s]][f][c] = rvg[s];
+    for (int s = 0; s < NP; ++s) sm.rvg[BMPC_STEP(s)][f][c] = rvg[s];
     sync_all();                                 // (also: the shared tables of the set-up, the iteration's exchange vectors are dead)
     int co = c;
     BMPC_OPAQUE(co);
@@ -503,7 +539,7 @@ stage_body(const DevParams& P, const int B,
     // derivation.  Here the wrench space is the ACCELERATION space a = E gamma: L~ = L E^-1, Ft = E^-T F E^-1.
 #pragma unroll 1
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       const float muf = sm.muf[j][f];
       float rf[2][3];
 #pragma unroll
@@ -894,12 +930,12 @@ stage_body(const DevParams& P, const int B,
   // exact axg and err from x (f64): err = e0 + Gam_t W x by two prefix sums over the steps
   auto refresh = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < NP; ++s) sm.u.itv.wg[js[s]][f][c] = xo[s];
+    for (int s = 0; s < NP; ++s) sm.u.itv.wg[BMPC_STEP(s)][f][c] = xo[s];
     BMPC_WAVE_SYNC();
     RT v2[NP];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       RT xblk[2][6], gu[6];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
@@ -936,12 +972,12 @@ stage_body(const DevParams& P, const int B,
     prefix_incl(v2);                            // (w, v) part of the state response (zero for n < 6)
     // (e, p) part: sum_{i <= j} C_i xi2_{i-1}: the lanes n < 6 need xi2 of the step before, other coordinates
 #pragma unroll
-    for (int s = 0; s < NP; ++s) sm.u.itv.lam[js[s]][n] = v2[s];
+    for (int s = 0; s < NP; ++s) sm.u.itv.lam[BMPC_STEP(s)][n] = v2[s];
     sync_all();                                 // (the step before may belong to another wave)
     RT v1[NP];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       RT d = 0;
       if (n < 6 && j > 0) {
         if (n < 3) d = dt * (sm.Rv[j][3 * n] * sm.u.itv.lam[j - 1][6] + sm.Rv[j][3 * n + 1] * sm.u.itv.lam[j - 1][7] + sm.Rv[j][3 * n + 2] * sm.u.itv.lam[j - 1][8]);
@@ -1008,12 +1044,12 @@ stage_body(const DevParams& P, const int B,
       for (int s = 0; s < NP; ++s) v[s] = (RT)2 * (RT)P.Q[n] * err[s];
       suffix_incl(v);                           // n < 6: lam1;  n >= 6: the own part of lam2
 #pragma unroll
-      for (int s = 0; s < NP; ++s) sm.u.itv.lam[js[s]][n] = v[s];
+      for (int s = 0; s < NP; ++s) sm.u.itv.lam[BMPC_STEP(s)][n] = v[s];
       BMPC_WAVE_SYNC();
       RT cpl[NP];                               // C_{i}' lam1_{i} of the steps i > j enters lam2_j
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
-        const int j = js[s];
+        const Step j = BMPC_STEP(s);
         RT d = 0;
         if (n >= 9) d = dt * sm.u.itv.lam[j][n - 6];
         else if (n >= 6) {
@@ -1026,14 +1062,14 @@ stage_body(const DevParams& P, const int B,
       suffix_excl(cpl);
 #pragma unroll
       for (int s = 0; s < NP; ++s)
-        if (n >= 6) sm.u.itv.lam[js[s]][n] = v[s] + cpl[s];
+        if (n >= 6) sm.u.itv.lam[BMPC_STEP(s)][n] = v[s] + cpl[s];
     }
     // --- P1: row residuals w = y + rho (A x - z)
     RT wb[NP];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       wb[s] = yb[s] + widen(rvb[s]) * (xo[s] - zb[s]);
-      sm.u.itv.wg[js[s]][f][c] = yg[s] + widen(rvg[s]) * (axg[s] - zg[s]);
+      sm.u.itv.wg[BMPC_STEP(s)][f][c] = yg[s] + widen(rvg[s]) * (axg[s] - zg[s]);
     }
     BMPC_WAVE_SYNC();
     BMPC_SSTAMP(0)
@@ -1046,7 +1082,7 @@ stage_body(const DevParams& P, const int B,
       const int i1 = a3 == 2 ? 0 : a3 + 1, i2 = a3 == 0 ? 2 : a3 - 1;
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
-        const int j = js[s];
+        const Step j = BMPC_STEP(s);
         RT l2[6], wq[6], iw[9];
 #pragma unroll
         for (int k = 0; k < 6; ++k) { l2[k] = sm.u.itv.lam[j][6 + k]; wq[k] = sm.u.itv.wg[j][f][k]; }
@@ -1077,7 +1113,7 @@ stage_body(const DevParams& P, const int B,
     float ddk[NP];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       float rj[2][6], lcol[6], kg[6];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
@@ -1133,7 +1169,7 @@ stage_body(const DevParams& P, const int B,
       // r_i = M_i' [0; bt_i] = Kn_i' bt_i: per step, by the step's own lanes
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
-        const int j = js[s];
+        const Step j = BMPC_STEP(s);
         float acc = 0.f;
         if (sreal[s]) {
 #pragma unroll
@@ -1231,7 +1267,7 @@ stage_body(const DevParams& P, const int B,
       // w = Sinv g, one component per lane pair (both lanes of a pair compute the same value); it replaces bt
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
-        const int j = js[s];
+        const Step j = BMPC_STEP(s);
         float acc = 0.f;
 #pragma unroll
         for (int m = 0; m < 6; ++m) acc = fmaf(sm.Sinv[j][c][m], sm.u.itv.gs[j][m], acc);
@@ -1333,7 +1369,7 @@ stage_body(const DevParams& P, const int B,
     float dstep[NP];                          // d_f[c] = (null-space part) + L~ a
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       float gm[6], lg[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -1354,7 +1390,7 @@ stage_body(const DevParams& P, const int B,
     for (int b = 0; b < 6; ++b) gub[b] = (float)sm.Gu[c][b];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
-      const int j = js[s];
+      const Step j = BMPC_STEP(s);
       float db[6];
 #pragma unroll
       for (int i = 0; i < 6; i += 2) {
@@ -1503,7 +1539,7 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
   for (int s = 0; s < NP; ++s) {
     if (!(sreal[s] && lane_real)) continue;
-    const int j = js[s];
+    const Step j = BMPC_STEP(s);
     float* uo = controls + ((size_t)inst * H + j) * 12;
     const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
     uo[pos] = (float)xo[s];
@@ -1528,6 +1564,7 @@ stage_body(const DevParams& P, const int B,
   }
 #undef BMPC_SSTAMP
 #undef BMPC_PASS_FENCE
+#undef BMPC_STEP
 }
 
 #define BMPC_STAGE_ARGS                                                                                            \
