@@ -50,6 +50,7 @@ if ROOT not in sys.path:
 
 MAX_CPU_WORKERS = 16
 PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_FP64_TFLOPS = 78.6           # MI355X fp64 vector peak (AMD spec sheet: half the fp32 vector rate; the guide lists no fp64 figure)
 
 
 def parse_args(argv=None):
@@ -489,7 +490,7 @@ def run_rank(args):
         ach = fl_r * B / (kernel_ms * 1e-3) / 1e12
         # HBM bytes per launch and the MFMA share need rocprofv3 --pmc passes (tools/profile_round.sh -> profiles/); what
         # is replayed here was measured with THESE kernel sources and this path, or it is refused
-        traffic, traffic_source, mfma_ops = None, None, None
+        traffic, traffic_source, mfma_ops, hw_flops = None, None, None, None
         ksha = kernel_source_hash()
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
@@ -501,6 +502,7 @@ def run_rank(args):
                             continue
                         traffic = pm["traffic_bytes_per_launch"]
                         mfma_ops = pm.get("sq_per_launch", {}).get("SQ_INSTS_VALU_MFMA_MOPS_F32")
+                        hw_flops = pm.get("valu_flops_per_launch")
                         traffic_source = "replayed from " + pm.get("source", "profiles/pmc_summary.json") + \
                                          " (rocprofv3 --pmc passes of this command; not measured in this run)"
         except (OSError, ValueError, KeyError, TypeError):
@@ -529,6 +531,14 @@ def run_rank(args):
                          "frac": ach / PEAK_FP32_TFLOPS,
                          "achieved_survey_formula": ach_s, "frac_survey_formula": ach_s / PEAK_FP32_TFLOPS,
                          "mfma_util": 0.0, "mfma_ops_counter": mfma_ops,
+                         "valu_flops_counter": (None if not hw_flops else {
+                             "f32_per_launch": hw_flops["f32"], "f64_per_launch": hw_flops["f64"],
+                             "tflops": (hw_flops["f32"] + hw_flops["f64"]) / (kernel_ms * 1e-3) / 1e12,
+                             # time the counted flops would take at the two vector peaks, over the launch duration
+                             "frac_of_vector_peak": (hw_flops["f32"] / (PEAK_FP32_TFLOPS * 1e12) + hw_flops["f64"] / (PEAK_FP64_TFLOPS * 1e12)) / (kernel_ms * 1e-3),
+                             "what": "every vector flop the kernel issued (SQ_INSTS_VALU_FLOPS_FP32/_FP64 x 64 lanes, replayed from "
+                                     "profiles/pmc_summary.json like `traffic`): redundant and masked-lane work included, so an upper "
+                                     "bound of the useful flops that `achieved` counts"}),
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_sha": ksha,
                          "kernel": (f"bmpc::solve_kernel<{h}>" if path_used == "dense" else f"bmpc::stage_kernel<{stage_variant(h)[0]}, {stage_variant(h)[1]}>"),
                          "kernel_ms": kernel_ms,

@@ -27,7 +27,7 @@ for d in sorted(glob.glob(os.path.join(src, "cfg*"))):
         rows = open(f).read().splitlines()
         keep = [rows[0]] + [r for r in rows[1:] if "solve_kernel" in r or "stage_kernel" in r][:3]
         open(os.path.join(dst, f"{tag}_{c}_kernel_trace_head.csv"), "w").write("\n".join(keep) + "\n")
-    for p in ("fetch", "write", "sq1", "sq2"):
+    for p in ("fetch", "write", "sq1", "sq2", "flops"):
         for f in newest(os.path.join(d, "pmc_" + p, "**", "*counter_collection.csv")):
             rows = list(csv.reader(open(f)))
             keep = [rows[0]] + [r for r in rows[1:] if "solve_kernel" in r[8] or "stage_kernel" in r[8]]

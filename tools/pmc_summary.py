@@ -35,9 +35,15 @@ for c in cfgs:
         s["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (units KB -> x1024), mean per launch. "
                      "FETCH_SIZE is NOT doubled: the gfx950 x2 correction is calibrated for 16-B/lane coalesced streams, this kernel reads dwords.")
     sq = {}
-    for p in ("pmc_sq1", "pmc_sq2"):
+    for p in ("pmc_sq1", "pmc_sq2", "pmc_flops"):
         sq.update({k: v[0] for k, v in counters(os.path.join(o, p)).items()})
     s["sq_per_launch"] = sq
+    if "SQ_INSTS_VALU_FLOPS_FP32" in sq:
+        # the counters count flops per LANE of a wave instruction (FMA 2, packed FMA 4, ...), whatever the EXEC mask: x 64
+        s["valu_flops_per_launch"] = {"f32": 64.0 * (sq["SQ_INSTS_VALU_FLOPS_FP32"] + sq.get("SQ_INSTS_VALU_FLOPS_FP32_TRANS", 0.0)),
+                                      "f64": 64.0 * (sq.get("SQ_INSTS_VALU_FLOPS_FP64", 0.0) + sq.get("SQ_INSTS_VALU_FLOPS_FP64_TRANS", 0.0)),
+                                      "note": "SQ_INSTS_VALU_FLOPS_FP32/_FP64 (+ _TRANS) x 64 lanes: every vector flop the kernel issues, "
+                                              "redundant and masked-lane work included (an upper bound of the useful flops)"}
     summ.append(s)
 json.dump(summ, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 for s in summ:

@@ -5,6 +5,7 @@
 #   trace/ ... kernel_stats    rocprofv3 --kernel-trace --stats of the same command
 #   pmc_fetch/, pmc_write/     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no tracing)
 #   pmc_sq1/, pmc_sq2/         SQ counters (wave cycles, waits, instruction mix, LDS activity / bank conflicts)
+#   pmc_flops/                 the hardware's own count of vector flops (SQ_INSTS_VALU_FLOPS_FP32 / _FP64: per lane, x64 per wave)
 #   phase_cycles.txt           in-kernel stamps (config 2 only)
 # and gpurun_out/prof_<tag>/pmc_summary.json, the list bench.py replays as roofline.traffic.
 # The program after `--` is python3 itself (the profiler's preloaded library initialises the GPU: no env/bash hop).
@@ -25,7 +26,8 @@ for c in $cfgs; do
   echo "cfg$c trace ok"
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
               "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-              "sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_SCA"; do
+              "sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_SCA" \
+              "flops SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64_TRANS"; do
     set -- $pass; name=$1; shift
     (cd /tmp && rocprofv3 --pmc $@ --output-format csv -d "$o/pmc_$name" -- python3 "$repo/bench.py" --config $c $extra --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2> "$o/pmc_$name.err") || { echo "pmc $name cfg$c failed"; tail -3 "$o/pmc_$name.err"; }
     echo "cfg$c pmc $name done"
