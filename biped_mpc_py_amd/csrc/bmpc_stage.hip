@@ -166,6 +166,7 @@ struct alignas(16) StageSmem {
   alignas(16) float Pm[12][12];   // Riccati recursion: cost-to-go
   alignas(16) float Zm[12][12];   //                    Schur complement (blocks 12, 22; Z11 replaces Pi11 in Pm)
   alignas(16) float Tm[6][6];     //                    S^-1 Ft
+  alignas(16) float Sm[6][6];     //                    S = Ft_i + Pi22 of the step the recursion reaches next (lower triangle)
   float q2[12];                   // 2 Q
   // step data
   StepArr<RT[9], HS, G> Iwi;               // world inverse inertia
@@ -718,6 +719,11 @@ stage_body(const DevParams& P, const int B,
     sync_all();                                 // every step's Ft is in place
     if (wv == 0) {                              // (wave-uniform)
       for (int e = l; e < 144; e += 64) sm.Pm[e / 12][e % 12] = 0.f;
+      if (l < 36) {                             // S of the last step: Ft + Pi22 with P = 0 (same sum order as below)
+        const int a = l / 6, b2 = l % 6;
+        const float ft = sm.Kn[H - 1][(6 * a + b2) / 12][(6 * a + b2) % 12];
+        sm.Sm[a][b2] = ft + 0.f + (a == b2 ? sm.q2[6 + a] : 0.f);
+      }
       BMPC_WAVE_SYNC();
       const float dtf = (float)P.dt;
       const int jn = l < 24 ? l : 23;           // column of [M | Ft | I] this lane solves (lanes 24.. repeat column 23)
@@ -740,6 +746,15 @@ stage_body(const DevParams& P, const int B,
         }
       };
       // Ft_i[a][b] sits in the first 36 floats of Kn_i until the gain overwrites them
+      // loop-invariant pieces of 2Q, read once (the compiler does not hoist LDS loads over the recursion's stores)
+      float q_za[2], q_zb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ro = z_blk[t] == 2 ? 6 : 0;
+        q_za[t] = sm.q2[ro + z_a[t]]; q_zb[t] = sm.q2[ro + z_b[t]];
+      }
+      const float q_pk = sm.q2[6 + pk];
+      const float q_col = (jn >= 6 && jn < 12) ? sm.q2[jn] : (jn >= 18 ? 1.f : 0.f);   // unit part of the right-hand side column
 #define BMPC_FT(a, b) sm.Kn[i][(6 * (a) + (b)) / 12][(6 * (a) + (b)) % 12]
 #pragma unroll 1
       for (int i = H - 1; i >= 0; --i) {
@@ -749,39 +764,36 @@ stage_body(const DevParams& P, const int B,
         {
           float S[6][6], rhs[6], x[6];
           {
-            float ftl[6][6], pml[6][6], qd[6];
-            // right-hand side: column jn of [Pi21 | Pi21 C + Pi22 | Ft | I], by address
+            // S = Ft_i + Pi22 was summed by stage R4 of the step before (Sm).  Right-hand side: column jn of
+            // [Pi21 | Pi21 C + Pi22 | Ft | I] = base + (Pi21 C) + unit part, every lane the same instructions: the base column
+            // by address (Pi21, Pi22, Ft or zeros), the C product with zero coefficients where the column has none
             const int k = jn < 12 ? (jn < 6 ? jn : jn - 6) : 0;
             int row[3];
             float cf[3];
             ctriple(i, k, row, cf);
-            const float sel_m1 = jn < 6 ? 1.f : 0.f, sel_m2 = (jn >= 6 && jn < 12) ? 1.f : 0.f;
-            const float sel_ft = (jn >= 12 && jn < 18) ? 1.f : 0.f;
+            const bool m2 = jn >= 6 && jn < 12;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) cf[t] = m2 ? cf[t] : 0.f;
             const int kf = (jn >= 12 && jn < 18) ? jn - 12 : 0, ki = jn >= 18 ? jn - 18 : -1;
-            float p21[6], p22[6], pc0[6], pc1[6], pc2[6], ftc[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-              qd[a] = sm.q2[6 + a];
-#pragma unroll
-              for (int b2 = 0; b2 <= a; ++b2) { ftl[a][b2] = BMPC_FT(a, b2); pml[a][b2] = sm.Pm[6 + a][6 + b2]; }
-            }
-            const float qk2 = sm.q2[6 + k];
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-              p21[m] = sm.Pm[6 + m][k];                                 // Pi21[m][k]
-              p22[m] = sm.Pm[6 + m][6 + k];
-              pc0[m] = sm.Pm[6 + m][row[0]]; pc1[m] = sm.Pm[6 + m][row[1]]; pc2[m] = sm.Pm[6 + m][row[2]];
-              ftc[m] = sm.Kn[i][(6 * m + kf) / 12][(6 * m + kf) % 12];
-            }
-            BMPC_SCHED_BARRIER();
+            const float* bp = jn < 6 ? &sm.Pm[6][jn] : (jn < 12 ? &sm.Pm[6][jn] : (jn < 18 ? &sm.Kn[i][0][kf] : &sm.zblk[0]));
+            const int bs = jn < 12 ? 12 : (jn < 18 ? 6 : 0);     // (Ft_i[m][kf] sits at flat offset 6 m + kf of Kn_i)
+            const float dq = q_col;
+            const int dm = m2 ? k : ki;
+            float base[6], pc0[6], pc1[6], pc2[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-              for (int b2 = 0; b2 <= a; ++b2) S[a][b2] = ftl[a][b2] + pml[a][b2] + (a == b2 ? qd[a] : 0.f);
+              for (int b2 = 0; b2 <= a; ++b2) S[a][b2] = sm.Sm[a][b2];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+              base[m] = bp[m * bs];
+              pc0[m] = sm.Pm[6 + m][row[0]]; pc1[m] = sm.Pm[6 + m][row[1]]; pc2[m] = sm.Pm[6 + m][row[2]];
+            }
+            BMPC_SCHED_BARRIER();
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
               const float pc = pc0[m] * cf[0] + pc1[m] * cf[1] + pc2[m] * cf[2];
-              rhs[m] = sel_m1 * p21[m] + sel_m2 * (pc + p22[m] + (m == k ? qk2 : 0.f)) + sel_ft * ftc[m] + (m == ki ? 1.f : 0.f);
+              rhs[m] = (pc + base[m]) + (m == dm ? dq : 0.f);
             }
           }
           BMPC_WAVE_SYNC();                       // Ft_i consumed by every lane before K_i lands on it
@@ -806,7 +818,7 @@ stage_body(const DevParams& P, const int B,
             const int rs = blk == 0 ? 12 : 6;
             const float* rbase = blk == 0 ? &sm.Kn[i][0][0] : &sm.Tm[0][0];
             const int ro = blk == 2 ? 6 : 0;
-            qa2[t] = sm.q2[ro + a]; qb2[t] = sm.q2[ro + b];
+            qa2[t] = q_za[t]; qb2[t] = q_zb[t];
             pab[t] = sm.Pm[a][b]; pba[t] = sm.Pm[b][a];
             rda[t] = rbase[a * rs + b]; rdb[t] = rbase[b * rs + a];      // (the 2Q diagonal of Pi22 meets these)
 #pragma unroll
@@ -844,6 +856,8 @@ stage_body(const DevParams& P, const int B,
           ctriple(i, pk2, rb, cb);
           ctriple(i, qk, rq, cq);
           float z_v = sm.Zm[6 + pk][6 + pk2], z_w = sm.Zm[6 + pk2][6 + pk], z_q = sm.Zm[qa][6 + qk];
+          const int inx = i > 0 ? i - 1 : 0;
+          const float ft_next = sm.Kn[inx][(6 * pk + pk2) / 12][(6 * pk + pk2) % 12];      // Ft of the step reached next
           float zq12[3], zr12[3], zbk[3], zak[3], pab[3][3], pba[3][3], pq[3];
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
@@ -876,7 +890,11 @@ stage_body(const DevParams& P, const int B,
             p12 = vq;
           }
           BMPC_WAVE_SYNC();                       // (emulation: all reads of Pm / Zm before the stores)
-          if (l < 36) sm.Pm[6 + pk][6 + pk2] = p22;
+          if (l < 36) {
+            sm.Pm[6 + pk][6 + pk2] = p22;
+            if (i > 0)                              // S of step i - 1: Ft + Pi22 (Pi22 = 2Q + P22), same sum order as the first step's
+              sm.Sm[pk][pk2] = ft_next + p22 + (pk == pk2 ? q_pk : 0.f);
+          }
           if (l >= 28) { sm.Pm[qa][6 + qk] = p12; sm.Pm[6 + qk][qa] = p12; }
         }
         BMPC_WAVE_SYNC();
