@@ -1030,3 +1030,24 @@ def test_rescue_pass_recovers_what_the_dense_sweep_loses():
     sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=8, solver_options=dict(path=PATH_STAGE, rescue=RESCUE_ON))
     assert sol._lib.bmpc_rescue_enabled(sol._h) == 0
     sol.close()
+
+
+@pytest.mark.parametrize("h,path,B", [(10, PATH_DENSE, 2048), (20, PATH_DENSE, 1024), (24, PATH_STAGE, 1024), (40, PATH_STAGE, 1024)])
+def test_runs_are_bitwise_reproducible(h, path, B):
+    """The same batch solved four times gives the same bits (controls, states, iteration counts): enough instances to put
+    more than one wave on a SIMD / several workgroups on a CU, which is where an exchange without its barrier, or a
+    register shared by mistake, shows as a run-to-run difference (`profiles/r03_determinism.txt`)."""
+    import biped_mpc_py_amd as bm
+    s = util.synth_batch(B, h, 3, gait="walking", vx_cmd=True, per_step_mu=(h >= 20))
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(path=path))
+    first = None
+    for _ in range(4):
+        st, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])
+        assert int((info["status"] != 0).sum()) == 0
+        if first is None:
+            first = (st, u, info["iters"].copy())
+        else:
+            assert np.array_equal(u, first[1]) and np.array_equal(st, first[0]) and np.array_equal(info["iters"], first[2])
+    sol.close()
