@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -51,7 +51,7 @@ class CParams(C.Structure):
         ("eps_pri", C.c_double), ("eps_dua", C.c_double),
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
         ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("warm_adapt_start", C.c_int32),
-        ("path", C.c_int32), ("penalty_mode", C.c_int32), ("rescue", C.c_int32),
+        ("path", C.c_int32), ("penalty_mode", C.c_int32), ("rescue", C.c_int32), ("accel", C.c_int32),
         ("kp", C.c_double * 9), ("kd", C.c_double * 9), ("swingHeight", C.c_double), ("hip_offset", C.c_double * 3),
     ]
 

@@ -115,6 +115,7 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   d->lt = p.lt - 0.01;                       // REF:254
   d->lh = p.lh - 0.02;                       // REF:255
   d->alpha = p.alpha;
+  d->accel = p.accel ? 1 : 0;
   for (int i = 0; i < 12; ++i) {
     d->x_cmd[i] = p.x_cmd[i];
     d->Q[i] = p.Q[i];
@@ -412,6 +413,7 @@ int bmpc_default_params(bmpc_params* p, int h) {
   p->adapt_every = (h <= 12 || h > 20) ? 10 : 20;
   p->adapt_start = (h < 20 || h > 20) ? 10 : 20;
   p->rescue = BMPC_RESCUE_AUTO;
+  p->accel = 1;
   p->warm_adapt_start = 5;                                            // (tools/warm_sweep.py)
   p->kp[0] = p->kp[4] = p->kp[8] = 500;                               // REF:30
   p->kd[0] = p->kd[4] = p->kd[8] = 10;                                // REF:31

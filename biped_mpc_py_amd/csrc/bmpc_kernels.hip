@@ -94,6 +94,7 @@ struct DevParams {
   double x_cmd[12], Q[12], R2[12], Iinv[9];    // R2 = 2 R;  Iinv = inverse body inertia
   double f_max[3], f_min[3], tau_max[3], tau_min[3];
   float rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m, eps_pri, eps_dua, kappa;
+  int accel;                                   // secant extrapolation of the iterate at the stopping tests (dense family)
 };
 
 struct DebugOut {            // all nullable, fp64, device pointers
@@ -217,7 +218,10 @@ struct alignas(16) Smem {
   RT GuT[6][6];
   RT qtl[Dims<H>::NW];       // wrench-space gradient at x = 0 (constant term of gb; only the exact rebuilds read it)
   float eyz[6];              // body y and z axes in the world frame (columns 1, 2 of eul2rotm(x_fb))
-  float red[2][6][Dims<H>::NWV];
+  float red[2][H == 12 ? 6 : 8][Dims<H>::NWV];
+  float aag[H == 12 ? 0 : Dims<H>::NT][7];                   // secant extrapolation: a lane's state change (x, zb, zg, yb, yg, A x, gradient), kept from
+                                               // the iteration before a stopping test, and over the test's reduction
+                                               // (not at h = 12: the 3.8 KB would cost that kernel its fourth instance per CU)
 };
 
 __device__ __forceinline__ int pair_index(int i, int j) { return i * (i - 1) / 2 + j; }   // i > j
@@ -238,6 +242,21 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 #endif
+#ifndef BMPC_EMU
+// sum over a wave, in a FIXED order (the same DPP tree as wave_umax: within rows of 16 by shifts of 1, 2, 4, 8, then the
+// rows): bitwise reproducible from run to run
+__device__ __forceinline__ float wave_sum(float v) {
+#define BMPC_DPP_ADD(ctrl) { v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true)); }
+  BMPC_DPP_ADD(0x111)   // row_shr:1
+  BMPC_DPP_ADD(0x112)   // row_shr:2
+  BMPC_DPP_ADD(0x114)   // row_shr:4
+  BMPC_DPP_ADD(0x118)   // row_shr:8   -> lane 15 of each row holds the row sum
+  BMPC_DPP_ADD(0x142)   // row_bcast:15 -> lane 31 / 63: rows 0-1 / 2-3
+  BMPC_DPP_ADD(0x143)   // row_bcast:31 -> lane 63: whole wave
+#undef BMPC_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#endif
 // max over the workgroup of NV such values at once; the waves combine through LDS.  All threads call.  ONE barrier:
 // the caller alternates between two `red` buffers, so a buffer is rewritten only after another barrier.
 template <int NT, int NV>
@@ -256,6 +275,35 @@ __device__ __forceinline__ void block_max(float (&v)[NV], float (*red)[NT / 64])
 #pragma unroll
     for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
     v[q] = __uint_as_float(m);
+  }
+}
+
+// the same exchange with NS sums behind the NV maxima (v[NV .. NV + NS - 1]; waves added in index order)
+template <int NT, int NV, int NS>
+__device__ __forceinline__ void block_max_sum(float (&v)[NV + NS], float (*red)[NT / 64]) {
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = __uint_as_float(wave_umax(__float_as_uint(v[q])));
+#pragma unroll
+  for (int q = NV; q < NV + NS; ++q) v[q] = wave_sum(v[q]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < NV + NS; ++q) red[q][w] = v[q];
+  }
+  sync_workgroup();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    unsigned m = __float_as_uint(red[q][0]);
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2) { const unsigned o = __float_as_uint(red[q][w2]); m = m > o ? m : o; }
+    v[q] = __uint_as_float(m);
+  }
+#pragma unroll
+  for (int q = NV; q < NV + NS; ++q) {
+    float a = red[q][0];
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2) a += red[q][w2];
+    v[q] = a;
   }
 }
 
@@ -1019,6 +1067,13 @@ solve_body(const DevParams& P, const int B,
   const int check_every = P.check_every > 0 ? P.check_every : 1;
   int next_check = 2 * check_every;
   int n_red = 0;
+  // Secant extrapolation (Anderson acceleration with memory one) at the stopping tests: the ADMM step is a fixed-point map
+  // w -> T(w) on w = (x, z, y); with g = T(w) - w of two consecutive iterations, w <- T(w) - gamma g,
+  // gamma = <g - g', g> / |g - g'|^2, is the secant step on the residual.  It costs two sums in the reduction the stopping test
+  // pays for anyway and takes 6 % of the iterations AND of the factorisations off a solve (the model, oracle/ws_model.py:
+  // 55.5 -> 52.5 / 5.80 -> 5.46 at h = 10).  The carried products A x and the gradient are linear in x and follow with the
+  // same gamma.  g' is kept from the iteration before the test only; a factorisation in between drops it.
+  bool aa_have = false;
   // exact rebuild of the carried products every REFRESH_ITERS iterations (at the first stopping test from there
   // on; identical iterates and parity for a rebuild at every test, every second and every fourth on every test set)
   constexpr int REFRESH_ITERS = 20;
@@ -1123,6 +1178,7 @@ solve_body(const DevParams& P, const int B,
       factor();
       ++nfac;
       need_factor = false;
+      aa_have = false;                         // another map: the stored state change belongs to the old one
     }
     if constexpr (PROF) t_last = clock64();
     // --- P0: row residuals w = y + rho (A x - z); publish them and the gradient
@@ -1237,6 +1293,12 @@ solve_body(const DevParams& P, const int B,
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f, slw = 0.f;   // residual statistics: only where the stopping test runs
     const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // workgroup-uniform
+    constexpr bool AA = (H != 12);
+    constexpr int AA_MAX_FACTOR = 8;             // an instance still re-classifying after that is cycling between active sets: no extrapolation
+#define AA_SLOT(x) (H == 12 ? 0 : (x))
+    const bool aa_keep = AA && P.accel != 0 && (it + 2 == next_check);           // the iteration before a stopping test
+    const bool aa_now = AA && P.accel != 0 && check_now && aa_have && (it + 1 < P.max_iter) && nfac <= AA_MAX_FACTOR;
+    float aa1 = 0.f, aa2 = 0.f;
     float ginc = 0.f;
     if (valid) {
       float gm[6];
@@ -1261,6 +1323,7 @@ solve_body(const DevParams& P, const int B,
       if constexpr (NG % 2 == 1) gq[NG - 1] = gsrc[NG - 1];
       BMPC_SCHED_BARRIER();
       RT st_pb, st_pg, st_x, st_g, st_dx;     // residual statistics inputs (used at stopping tests)
+      RT d_zb, d_zg, d_yb, d_yg, d_ax;         // state change of this iteration (by-products of the update)
       {
         f2 dd = ddk;                            // {d_f[c], (G_f d_f)[c]}: the null-space part was formed in P3
 #pragma unroll
@@ -1274,7 +1337,9 @@ solve_body(const DevParams& P, const int B,
           const RT zr = alpha * ztb + (1 - alpha) * zb;
           const RT cand = zr + yb * irvb;
           const RT zn = fmin(fmax(cand, widen(lb)), widen(ub));
-          yb += widen(rvb) * (zr - zn);
+          d_yb = widen(rvb) * (zr - zn);
+          yb += d_yb;
+          d_zb = zn - zb;
           zb = zn;
           st_pb = ztb - zn;
         }
@@ -1283,11 +1348,14 @@ solve_body(const DevParams& P, const int B,
           const RT zr = alpha * ztg + (1 - alpha) * zg;
           const RT cand = zr + yg * irvg;
           const RT zn = fmin(cand, (RT)0);
-          yg += widen(rvg) * (zr - zn);
+          d_yg = widen(rvg) * (zr - zn);
+          yg += d_yg;
+          d_zg = zn - zg;
           zg = zn;
           st_pg = ztg - zn;
         }
         st_x = xto; st_g = ztg; st_dx = xto - xo;
+        d_ax = alpha * (ztg - axg);
         xo = alpha * xto + (1 - alpha) * xo;
         axg = alpha * ztg + (1 - alpha) * axg;
       }
@@ -1307,6 +1375,19 @@ solve_body(const DevParams& P, const int B,
         if constexpr (NG % 2 == 1) etail = Grow[NG - 1] * gq[NG - 1];
         ginc = ((e0.x + e0.y) + (e1.x + e1.y)) + etail;
       }
+      if (aa_keep || aa_now) {                  // (uniform)
+        const float ag[6] = {(float)(alpha * st_dx), (float)d_zb, (float)d_zg, (float)d_yb, (float)d_yg, (float)d_ax};
+        if (aa_now) {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const float d = ag[q] - sm.aag[AA_SLOT(l)][q];
+            aa1 = fmaf(d, ag[q], aa1);
+            aa2 = fmaf(d, d, aa2);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sm.aag[AA_SLOT(l)][q] = ag[q];      // (own slot: read back by this lane after the reduction)
+      }
       if (check_now) {
         // a real (uniform) branch: predicated, this costs ~25 instructions in every iteration
         BMPC_FENCE();
@@ -1324,6 +1405,8 @@ solve_body(const DevParams& P, const int B,
     }
     ginc += pair_swap(ginc);
     gbl -= alpha * (RT)ginc;
+    if (aa_now) sm.aag[AA_SLOT(l)][6] = -(float)alpha * ginc;
+    if (aa_keep) aa_have = true;
     ++it;
     BMPC_STAMP(5)
     // --- stopping test and penalty re-classification (workgroup-uniform decisions).  Both need a reduction over
@@ -1358,10 +1441,18 @@ solve_body(const DevParams& P, const int B,
     // bounds the error.  An instance that fails this third test does not stop; it re-classifies at once (the penalty of
     // the lagging row comes down).  `slw` is formed in P5, with the other statistics.
     constexpr float SLOW_TOL = 1.0e-5f;
+    constexpr float AA_GAMMA_MAX = 100.f;       // a secant step beyond the one of a 0.99 contraction is not trusted
     bool force_adapt = false;
     if (check_now || adapt_do) {
-      float v5[6] = {rp, rs, nz, nx, chg, slw};
-      block_max<NT, 6>(v5, sm.red[n_red & 1]);
+      float v5[8] = {rp, rs, nz, nx, chg, slw, aa1, aa2};
+      if constexpr (AA) {
+        block_max_sum<NT, 6, 2>(v5, sm.red[n_red & 1]);
+      } else {
+        float v6[6] = {rp, rs, nz, nx, chg, slw};
+        block_max<NT, 6>(v6, sm.red[n_red & 1]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v5[q] = v6[q];
+      }
       ++n_red;
       if (check_now) {
         res_p = v5[0];
@@ -1388,6 +1479,23 @@ solve_body(const DevParams& P, const int B,
         irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
         need_factor = true;
       }
+      if (aa_now) {                             // (uniform; the instance goes on)
+        const float gam = v5[6] / v5[7];
+        if (v5[7] > 0.f && fabsf(gam) < AA_GAMMA_MAX) {      // (NaN fails the comparison: a degenerate secant is skipped)
+          const RT gr = (RT)gam;
+          float ag[7];
+#pragma unroll
+          for (int q = 0; q < 7; ++q) ag[q] = sm.aag[AA_SLOT(l)][q];
+          xo -= gr * (RT)ag[0];
+          zb = fmin(fmax(zb - gr * (RT)ag[1], widen(lb)), widen(ub));
+          zg = fmin(zg - gr * (RT)ag[2], (RT)0);
+          yb -= gr * (RT)ag[3];
+          yg -= gr * (RT)ag[4];
+          axg -= gr * (RT)ag[5];
+          gbl -= gr * (RT)ag[6];
+        }
+      }
+      aa_have = false;
     }
     BMPC_STAMP(6)
     BMPC_DRAIN_LDS();                           // nothing in flight across the back edge (see sync_workgroup)

@@ -45,7 +45,7 @@ class Biped:
 
 # solver knobs (bmpc_default_params): overridable through solver_options
 SOLVER_FIELDS = ("rho", "rho_eq_scale", "rho_lo", "rho_hi_f", "rho_hi_m", "kappa", "alpha", "eps_pri", "eps_dua",
-                 "max_iter", "check_every", "adapt_start", "adapt_every", "max_refactor", "warm_adapt_start", "path", "penalty_mode", "rescue")
+                 "max_iter", "check_every", "adapt_start", "adapt_every", "max_refactor", "warm_adapt_start", "path", "penalty_mode", "rescue", "accel")
 
 # bmpc_params.path (include/bmpc.h enum bmpc_path)
 PATH_AUTO, PATH_DENSE, PATH_STAGE = 0, 1, 2

@@ -64,6 +64,7 @@ class Params:
         self.eps_pri = 1e-7
         self.eps_dua = 1e-7
         self.max_refactor = 24
+        self.accel = True          # secant extrapolation at the stopping tests (bmpc_params.accel; dense family)
 
 
 def _skew(v):
@@ -291,9 +292,15 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     Gt_b = Gt.reshape(B, h, 6, h, 6).astype(rdt)
     qt_r = qt.reshape(B, h, 6).astype(rdt)
     n_it = iters if iters is not None else P.max_iter
+    # secant extrapolation (Anderson acceleration, memory one) as in bmpc_kernels.hip: g' = state change of the iteration
+    # before a stopping test, dropped by a factorisation in between
+    accel = bool(getattr(P, "accel", False)) and getattr(P, "solver", "dense") != "riccati"
+    aa_prev = None                                # (g' of every instance, flattened)
+    aa_prev_fac = None                            # n_factor when g' was taken
     it_done = np.full(B, n_it)
     active = np.ones(B, bool)
     for it in range(n_it):
+        n_factor_at_step = n_factor.copy()
         rvr = rv.astype(rdt)
         # residual (rdt), formed as ONE control-space vector so that it is small at convergence:
         #   r = W'(Gt W x + qt) + 2R x + A'(y + rho (A x - z))
@@ -348,6 +355,9 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
             if iters is None:
                 active &= ~done
         keep = active[:, None, None, None]
+        aa_g = None
+        if accel and ((it + 2) % P.check_every == 0 or (it + 1) % P.check_every == 0):
+            aa_g = np.concatenate([(xn - x).reshape(B, -1), (zn - z).reshape(B, -1), (yn - y).reshape(B, -1)], 1).astype(np.float32)
         x = np.where(keep, xn, x)
         z = np.where(keep, zn, z)
         y = np.where(keep, yn, y)
@@ -388,6 +398,24 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
                 rv = np.where(changed[:, None, None, None], rnew, rv)
                 L, Na, V = fac(rv)                                   # model: refactor all
                 n_factor += changed
+        # (end of the iteration) secant step at a stopping test for the instances that go on
+        if accel and aa_g is not None:
+            if (it + 1) % P.check_every == 0:
+                if aa_prev is not None and (it + 1) < P.max_iter:
+                    d = aa_g - aa_prev
+                    s1 = np.einsum("bn,bn->b", d, aa_g)
+                    s2 = np.einsum("bn,bn->b", d, d)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        gam = s1 / s2
+                    okg = active & (s2 > 0) & (np.abs(gam) < 100.0) & (aa_prev_fac == n_factor_at_step) & (n_factor_at_step <= 8)
+                    gam = np.where(okg, gam, 0.0).astype(rdt)
+                    n1, n2 = x.size // B, z.size // B
+                    x = x - gam[:, None, None, None] * aa_g[:, :n1].reshape(x.shape).astype(rdt)
+                    z = np.clip(z - gam[:, None, None, None] * aa_g[:, n1:n1 + n2].reshape(z.shape).astype(rdt), lr, ur)
+                    y = y - gam[:, None, None, None] * aa_g[:, n1 + n2:].reshape(y.shape).astype(rdt)
+                aa_prev = None
+            else:
+                aa_prev, aa_prev_fac = aa_g, n_factor_at_step
     # controls in reference order [f1 f2 m1 m2]
     ctrl = np.concatenate([x[:, :, 0, 0:3], x[:, :, 1, 0:3], x[:, :, 0, 3:6], x[:, :, 1, 3:6]], -1)
     wr = np.einsum("bhfij,bhfj->bhi", Wr, x).astype(dtp)                  # wrench per step

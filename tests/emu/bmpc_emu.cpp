@@ -102,6 +102,35 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
   wb.arrive_and_wait();
   return m;
 }
+// sum over the lane's wave in the order of the GPU's DPP tree (bmpc_kernels.hip wave_sum): inclusive scan inside rows of
+// 16 by shifts 1, 2, 4, 8 (zero where the source lane is outside the row), then row 1 += lane 15, rows 2, 3 += lane 31
+static float g_redf[1024];
+static inline float wave_sum(float v) {
+  std::barrier<>& wb = *g_wbar[threadIdx.x >> 6];
+  const int w0 = threadIdx.x & ~63, ln = threadIdx.x & 63;
+  for (int sh = 1; sh <= 8; sh <<= 1) {
+    g_redf[threadIdx.x] = v;
+    wb.arrive_and_wait();
+    const float o = ((ln & 15) >= sh) ? g_redf[threadIdx.x - sh] : 0.f;
+    wb.arrive_and_wait();
+    v += o;
+  }
+  g_redf[threadIdx.x] = v;
+  wb.arrive_and_wait();
+  const float b15 = ln >= 16 ? g_redf[w0 + ((ln >> 4) - 1) * 16 + 15] : 0.f;     // row_bcast:15, every row enabled
+  wb.arrive_and_wait();
+  v += b15;
+  g_redf[threadIdx.x] = v;
+  wb.arrive_and_wait();
+  const float b31 = ln >= 32 ? g_redf[w0 + 31] : 0.f;                            // row_bcast:31
+  wb.arrive_and_wait();
+  v += b31;
+  g_redf[threadIdx.x] = v;
+  wb.arrive_and_wait();
+  const float r = g_redf[w0 + 63];
+  wb.arrive_and_wait();
+  return r;
+}
 }  // namespace bmpc
 #define BMPC_WAVE_SYNC() g_wbar[threadIdx.x >> 6]->arrive_and_wait()
 #define BMPC_DRAIN_LDS() do { } while (0)
@@ -210,6 +239,7 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
     double rmin = p->R[0];
     for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p->R[i]);
     d.r2min = (float)(2 * rmin);
+    d.accel = p->accel ? 1 : 0;
   }
   if (!inv3(p->I, d.Iinv)) return -1;
   for (int i = 0; i < 3; ++i) {

@@ -163,7 +163,8 @@ def test_rescue_mode_is_a_solver_option_with_default_auto():
     from biped_mpc_py_amd.params import RESCUE_AUTO, RESCUE_OFF, RESCUE_ON
     assert (RESCUE_AUTO, RESCUE_OFF, RESCUE_ON) == (-1, 0, 1)
     cp = bm.pack_params(bm.MPC(), bm.Biped())
-    assert cp.rescue == RESCUE_AUTO
+    assert cp.rescue == RESCUE_AUTO and cp.accel == 1
+    assert bm.pack_params(bm.MPC(), bm.Biped(), solver_options=dict(accel=0)).accel == 0
     assert bm.pack_params(bm.MPC(), bm.Biped(), solver_options=dict(rescue=RESCUE_ON)).rescue == RESCUE_ON
     out = (C.c_double * 5)()
     assert _lib.load().bmpc_effective_penalties(C.byref(cp), out) == 0

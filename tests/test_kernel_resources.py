@@ -35,10 +35,11 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
                                      if k != "offset" and k != "size"}
     assert sorted(seen) == [8, 10, 12, 14, 16, 18, 20], seen
     for h, meta in seen.items():
-        # the BASELINE horizons hold everything in registers; h = 18 (54 floats of a row half next to the f64 state)
-        # is allowed a handful of spilled registers
-        assert int(meta["vgpr_spill_count"]) <= (0 if h in (8, 10, 12, 14, 16, 20) else 4), (h, meta)
-        if h != 18:
+        # everything in registers up to h = 16; the two longest dense horizons (54 / 60 floats of a row half next to the f64
+        # state) are allowed a handful of spilled registers -- set-up values stored once and reloaded at the stopping tests
+        # and the outputs (h = 20: 4 since the secant extrapolation; measured with it: -5.7 % kernel time)
+        assert int(meta["vgpr_spill_count"]) <= (0 if h in (8, 10, 12, 14, 16) else 4), (h, meta)
+        if h not in (18, 20):
             assert int(meta["private_segment_fixed_size"]) == 0, (h, meta)       # no scratch
         assert int(meta["vgpr_count"]) + meta["agpr_count"] <= 256, (h, meta)      # two waves per SIMD
         lds = int(meta["group_segment_fixed_size"])
