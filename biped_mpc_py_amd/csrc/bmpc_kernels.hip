@@ -1070,8 +1070,10 @@ solve_body(const DevParams& P, const int B,
   // Secant extrapolation (Anderson acceleration with memory one) at the stopping tests: the ADMM step is a fixed-point map
   // w -> T(w) on w = (x, z, y); with g = T(w) - w of two consecutive iterations, w <- T(w) - gamma g,
   // gamma = <g - g', g> / |g - g'|^2, is the secant step on the residual.  It costs two sums in the reduction the stopping test
-  // pays for anyway and takes 6 % of the iterations AND of the factorisations off a solve (the model, oracle/ws_model.py:
-  // 55.5 -> 52.5 / 5.80 -> 5.46 at h = 10).  The carried products A x and the gradient are linear in x and follow with the
+  // pays for anyway and takes 5 .. 7 % of the iterations AND of the factorisations off a solve (h = 10: 56.4 -> 53.4 / 5.86 ->
+  // 5.57; h = 20: 87.9 -> 81.4 / 4.75 -> 4.48; the model oracle/ws_model.py agrees to 0.1); A/B on one box -2.5 % kernel time at
+  // h = 10, -3.7 % at h = 20.  Memory two takes 9 % of the iterations but its 7 registers and 2.4 KB make the h = 10 kernel
+  // 1.3 % SLOWER than memory one (built, A/B-timed, not kept).  The carried products A x and the gradient are linear in x and follow with the
   // same gamma.  g' is kept from the iteration before the test only; a factorisation in between drops it.
   bool aa_have = false;
   // exact rebuild of the carried products every REFRESH_ITERS iterations (at the first stopping test from there
