@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+#include <type_traits>
 
 namespace bmpc {
 
@@ -144,7 +145,7 @@ struct alignas(16) StageSmem {
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
-  float red[2][6][NW];         // reductions across the waves
+  float red[2][8][NW];         // reductions across the waves (six maxima, two sums)
   // block-diagonal part of K^-1 (see bmpc_kernels.hip): L~ = L E^-1 (acceleration space), Kn = {Ka^-1, T Ka^-1}.
   // (no G images as in the dense kernels: an instance's LDS decides how many instances share a CU, and the step d
   //  is exchanged once per iteration instead)
@@ -928,6 +929,18 @@ stage_body(const DevParams& P, const int B,
 
   int nfac = 0;
   bool need_factor = true;
+  // Secant extrapolation at the stopping tests (bmpc_kernels.hip), in the form that needs no memory
+  // but NP registers: the secant coefficient is taken from the x part of the state alone (the model: 52.9 iterations against
+  // 53.0 with the full (x, z, y) metric), so the history is the x change of the iteration before a test; and at a test the
+  // update runs in two passes -- statistics first, from temporaries, the commit after the reduction, when gamma is known and
+  // the OLD state is still in its registers: nothing is parked.  Not with five steps per lane (no registers).
+  constexpr bool AA = NP <= 4;
+  const int AA_MAX_FACTOR = P.adapt_every <= 10 && H > 20 ? 16 : 8;   // (the long horizons re-classify twice as often: 8 factorisations are their mean)
+  constexpr float AA_GAMMA_MAX = 100.f;
+  bool aa_have = false;
+  float aa_gx[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) aa_gx[s] = 0.f;
 
   // ------------------------------------------------------------------ E. ADMM iterations
   RT xo[NP], zb[NP], zg[NP], yb[NP], yg[NP], axg[NP];
@@ -1052,6 +1065,7 @@ stage_body(const DevParams& P, const int B,
       factor();
       ++nfac;
       need_factor = false;
+      aa_have = false;                         // another map: the stored change belongs to the old one
     }
     if constexpr (PROF) t_last = clock64();
     // --- P0: adjoint of the tracking error: lam = sum_{i >= j} (A_{i+1} .. A_{j+1})' 2Q err_i (acceleration space);
@@ -1381,6 +1395,16 @@ stage_body(const DevParams& P, const int B,
     }
     sync_all();
     BMPC_SSTAMP(3)
+    // (penalty re-classification of step s from given (z, y) values: active rows move up by kappa towards their class
+    //  ceiling, inactive ones down towards rho_lo; damped after many factorisations -- bmpc_kernels.hip)
+    auto reclassify_v = [&](int s, RT zbv, RT ybv, RT zgv, RT ygv, float& nb, float& ng) __attribute__((always_inline)) {
+      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
+      const bool actb = (zbv <= (RT)lb[s] || zbv >= (RT)ub[s]) && ybv != (RT)0;
+      const bool actg = (zgv >= (RT)0) && ygv != (RT)0;
+      const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+      nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kap, hib) : fmaxf(rvb[s] / kap, P.rho_lo));
+      ng = actg ? fminf(rvg[s] * kap, hig) : fmaxf(rvg[s] / kap, P.rho_lo);
+    };
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f, slw = 0.f;
     const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // wave-uniform
@@ -1406,8 +1430,14 @@ stage_body(const DevParams& P, const int B,
     float gub[6];                             // row c of the mu-free general rows
 #pragma unroll
     for (int b = 0; b < 6; ++b) gub[b] = (float)sm.Gu[c][b];
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
+    const bool aa_keep = AA && P.accel != 0 && (it + 2 == next_check);           // the iteration before a stopping test
+    const bool aa_now = AA && P.accel != 0 && check_now && aa_have && (it + 1 < P.max_iter) && nfac <= AA_MAX_FACTOR;
+    const bool adapt_next = (it + 1 == next_adapt) && nfac <= P.max_refactor;    // this iteration ends on a re-classification
+    float aa1 = 0.f, aa2 = 0.f, chg_t = 0.f;
+    // one step of the update.  MODE 0: commit (an ordinary iteration); 1: the statistics of a stopping test from temporaries,
+    // nothing committed; 2: commit after the test's reduction, moved along the step by -gam (gam = 0: the plain update).
+    auto p5_step = [&](int s, auto mode_c, RT gam) __attribute__((always_inline)) {
+      constexpr int MODE = decltype(mode_c)::value;
       const Step j = BMPC_STEP(s);
       float db[6];
 #pragma unroll
@@ -1429,41 +1459,80 @@ stage_body(const DevParams& P, const int B,
       const RT xto = xo[s] - (RT)dd.x;
       const RT ztg = axg[s] - (RT)dd.y;
       const RT ztb = xto;
-      RT st_pb, st_pg;
+      RT st_pb, st_pg, znb, zng, ybn, ygn;
       {
         const RT zr = alpha * ztb + (1 - alpha) * zb[s];
         const RT cand = zr + yb[s] * irvb[s];
-        const RT zn = fmin(fmax(cand, widen(lb[s])), widen(ub[s]));
-        yb[s] += widen(rvb[s]) * (zr - zn);
-        zb[s] = zn;
-        st_pb = ztb - zn;
+        znb = fmin(fmax(cand, widen(lb[s])), widen(ub[s]));
+        ybn = yb[s] + widen(rvb[s]) * (zr - znb);
+        st_pb = ztb - znb;
       }
       {
         const RT zr = alpha * ztg + (1 - alpha) * zg[s];
         const RT cand = zr + yg[s] * irvg[s];
-        const RT zn = fmin(cand, (RT)0);
-        yg[s] += widen(rvg[s]) * (zr - zn);
-        zg[s] = zn;
-        st_pg = ztg - zn;
+        zng = fmin(cand, (RT)0);
+        ygn = yg[s] + widen(rvg[s]) * (zr - zng);
+        st_pg = ztg - zng;
       }
-      if (check_now && sreal[s]) {
-        rp = fmaxf(rp, fmaxf(fabsf((float)st_pb), fabsf((float)st_pg)));
-        {
-          const bool actb = (zb[s] <= (RT)lb[s] || zb[s] >= (RT)ub[s]) && yb[s] != (RT)0;
-          const bool actg = (zg[s] >= (RT)0) && yg[s] != (RT)0;
-          slw = fmaxf(slw, fmaxf((actb || eqb[s]) ? 0.f : rvb[s] * fabsf((float)st_pb), actg ? 0.f : rvg[s] * fabsf((float)st_pg)));
+      if constexpr (MODE != 2) {
+        if (check_now && sreal[s]) {
+          rp = fmaxf(rp, fmaxf(fabsf((float)st_pb), fabsf((float)st_pg)));
+          {
+            const bool actb = (znb <= (RT)lb[s] || znb >= (RT)ub[s]) && ybn != (RT)0;
+            const bool actg = (zng >= (RT)0) && ygn != (RT)0;
+            slw = fmaxf(slw, fmaxf((actb || eqb[s]) ? 0.f : rvb[s] * fabsf((float)st_pb), actg ? 0.f : rvg[s] * fabsf((float)st_pg)));
+          }
+          nz = fmaxf(nz, fmaxf(fabsf((float)xto), fabsf((float)ztg)));
+          rs = fmaxf(rs, fabsf((float)(xto - xo[s])));
+          // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
+          nx = fmaxf(nx, (xto == xto) ? fabsf((float)xto) : __builtin_inff());
         }
-        nz = fmaxf(nz, fmaxf(fabsf((float)xto), fabsf((float)ztg)));
-        rs = fmaxf(rs, fabsf((float)(xto - xo[s])));
-        // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
-        nx = fmaxf(nx, (xto == xto) ? fabsf((float)xto) : __builtin_inff());
       }
-      xo[s] = alpha * xto + (1 - alpha) * xo[s];
-      axg[s] = alpha * ztg + (1 - alpha) * axg[s];
-      // W x~ = W x - gamma exactly, so the tracking error follows the state response of the solve (f32 increment: it
-      // vanishes with the step; rebuilt exactly in f64 every REFRESH_ITERS iterations and before leaving)
-      err[s] -= alpha * (RT)xin;
+      if constexpr (MODE == 1) {
+        // the secant sums (x part of the state) and the "some penalty moves" flag, from the temporaries
+        if (sreal[s]) {
+          const float gx = -(float)alpha * dd.x;
+          const float d = gx - aa_gx[s];
+          aa1 = fmaf(d, gx, aa1);
+          aa2 = fmaf(d, d, aa2);
+          if (adapt_next) {
+            float nb, ng;
+            reclassify_v(s, znb, ybn, zng, ygn, nb, ng);
+            chg_t = ((nb != rvb[s]) | (ng != rvg[s])) ? 1.f : chg_t;
+          }
+        }
+      } else {
+        RT xn = alpha * xto + (1 - alpha) * xo[s];
+        RT an = alpha * ztg + (1 - alpha) * axg[s];
+        // W x~ = W x - gamma exactly, so the tracking error follows the state response of the solve (f32 increment: it
+        // vanishes with the step; rebuilt exactly in f64 every REFRESH_ITERS iterations and before leaving)
+        RT en = err[s] - alpha * (RT)xin;
+        if constexpr (MODE == 2) {
+          xn -= gam * (xn - xo[s]);
+          an -= gam * (an - axg[s]);
+          en -= gam * (en - err[s]);
+          znb = fmin(fmax(znb - gam * (znb - zb[s]), widen(lb[s])), widen(ub[s]));
+          zng = fmin(zng - gam * (zng - zg[s]), (RT)0);
+          ybn -= gam * (ybn - yb[s]);
+          ygn -= gam * (ygn - yg[s]);
+        }
+        xo[s] = xn; axg[s] = an; err[s] = en;
+        zb[s] = znb; yb[s] = ybn; zg[s] = zng; yg[s] = ygn;
+      }
       BMPC_PASS_FENCE(s);
+    };
+    const bool two_pass = AA && P.accel != 0 && check_now;      // (uniform) a stopping test with the extrapolation enabled
+    if (two_pass) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) p5_step(s, std::integral_constant<int, 1>{}, (RT)0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) p5_step(s, std::integral_constant<int, 0>{}, (RT)0);
+    }
+    if (aa_keep) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) aa_gx[s] = -(float)alpha * dstep[s];
+      aa_have = true;
     }
     ++it;
     BMPC_SSTAMP(4)
@@ -1472,17 +1541,14 @@ stage_body(const DevParams& P, const int B,
     if (adapt_now) next_adapt += P.adapt_every;
     const bool adapt_do = adapt_now && nfac <= P.max_refactor;
     auto reclassify = [&](int s, float& nb, float& ng) __attribute__((always_inline)) {
-      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
-      const bool actb = (zb[s] <= (RT)lb[s] || zb[s] >= (RT)ub[s]) && yb[s] != (RT)0;
-      const bool actg = (zg[s] >= (RT)0) && yg[s] != (RT)0;
-      const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-      nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kap, hib) : fmaxf(rvb[s] / kap, P.rho_lo));
-      ng = actg ? fminf(rvg[s] * kap, hig) : fmaxf(rvg[s] / kap, P.rho_lo);
+      reclassify_v(s, zb[s], yb[s], zg[s], yg[s], nb, ng);
     };
     bool force_adapt = false;
     if (check_now || adapt_do) {
       float chg = 0.f;
-      if (adapt_do) {
+      if (two_pass) {
+        chg = adapt_do ? chg_t : 0.f;           // (formed in the statistics pass: the state is not committed yet)
+      } else if (adapt_do) {
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
           float nb, ng;
@@ -1493,15 +1559,19 @@ stage_body(const DevParams& P, const int B,
       // (see bmpc_kernels.hip: the third stopping test -- the pull rho |z~ - z| of the inactive rows against the softest
       //  curvature; an instance that fails it re-classifies at once instead of stopping)
       constexpr float SLOW_TOL = 1.0e-5f;
-      float v5[6] = {rp, rs, nz, nx, chg, slw};
+      float v5[8] = {rp, rs, nz, nx, chg, slw, aa1, aa2};
 #pragma unroll
       for (int k = 0; k < 6; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
+      if (two_pass) {                           // (uniform) the two secant sums ride in the same exchange
+        v5[6] = wave_sum(v5[6]);
+        v5[7] = wave_sum(v5[7]);
+      }
       if constexpr (NW > 1) {                   // combine the waves (two buffers: a buffer is rewritten after another barrier)
         float (*red)[NW] = sm.red[n_red & 1];
         ++n_red;
         if (l == 0) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) red[k][wv] = v5[k];
+          for (int k = 0; k < 8; ++k) red[k][wv] = v5[k];
         }
         sync_workgroup();
 #pragma unroll
@@ -1510,6 +1580,13 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
           for (int w2 = 1; w2 < NW; ++w2) { const unsigned o = __float_as_uint(red[k][w2]); m = m > o ? m : o; }
           v5[k] = __uint_as_float(m);
+        }
+#pragma unroll
+        for (int k = 6; k < 8; ++k) {
+          float a2 = red[k][0];
+#pragma unroll
+          for (int w2 = 1; w2 < NW; ++w2) a2 += red[k][w2];
+          v5[k] = a2;
         }
       }
       if (check_now) {
@@ -1522,6 +1599,14 @@ stage_body(const DevParams& P, const int B,
         force_adapt = small && !done && !bad && nfac <= P.max_refactor && it < P.max_iter;
         const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
         next_check += far ? 2 * check_every : check_every;
+        if (two_pass) {                         // the commit of this iteration's update, along the secant where the instance goes on
+          float gam = v5[6] / v5[7];
+          const bool ext = aa_now && !done && !bad && v5[7] > 0.f && fabsf(gam) < AA_GAMMA_MAX;   // (NaN fails the comparison)
+          gam = ext ? gam : 0.f;
+#pragma unroll
+          for (int s = 0; s < NP; ++s) p5_step(s, std::integral_constant<int, 2>{}, (RT)gam);
+          aa_have = false;
+        }
         const bool rebuild = it >= next_refresh;
         if (rebuild) next_refresh = it + REFRESH_ITERS;
         if (bad || done || it == P.max_iter || rebuild) refresh();

@@ -120,9 +120,9 @@ typedef struct bmpc_params {
                                 lost an instance in 6 M and the launch would only cost ~1 %.  No effect on the stage path. */
   int32_t accel;             /* 1 (default) / 0: secant extrapolation of the iterate at the stopping tests (Anderson acceleration with
                                 memory one: w <- T(w) - gamma (T(w) - w), gamma from the last two state changes; two sums in the
-                                reduction the stopping test already pays for).  Dense family only (the stage family has no
-                                registers to keep a state change; not at h = 12): 5-7 % fewer iterations and factorisations, 1-4 % less
-                                kernel time.  Same fixed point. */
+                                reduction the stopping test already pays for).  Both families (not the dense kernel of h = 12 nor
+                                the stage kernel of h = 22 / 24: no LDS / registers for it): 5-7 % fewer iterations and
+                                factorisations up to h = 20, 2-5 % beyond, 1-4 % less kernel time.  Same fixed point. */
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
   double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
   double swingHeight;        /* REF:32 */

@@ -294,7 +294,8 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     n_it = iters if iters is not None else P.max_iter
     # secant extrapolation (Anderson acceleration, memory one) as in bmpc_kernels.hip: g' = state change of the iteration
     # before a stopping test, dropped by a factorisation in between
-    accel = bool(getattr(P, "accel", False)) and getattr(P, "solver", "dense") != "riccati"
+    accel = bool(getattr(P, "accel", False))
+    aa_x_only = getattr(P, "solver", "dense") == "riccati"      # the stage family's metric: the x part of the state alone
     aa_prev = None                                # (g' of every instance, flattened)
     aa_prev_fac = None                            # n_factor when g' was taken
     it_done = np.full(B, n_it)
@@ -403,11 +404,12 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
             if (it + 1) % P.check_every == 0:
                 if aa_prev is not None and (it + 1) < P.max_iter:
                     d = aa_g - aa_prev
-                    s1 = np.einsum("bn,bn->b", d, aa_g)
-                    s2 = np.einsum("bn,bn->b", d, d)
+                    nx_ = x.size // B if aa_x_only else d.shape[1]
+                    s1 = np.einsum("bn,bn->b", d[:, :nx_], aa_g[:, :nx_])
+                    s2 = np.einsum("bn,bn->b", d[:, :nx_], d[:, :nx_])
                     with np.errstate(divide="ignore", invalid="ignore"):
                         gam = s1 / s2
-                    okg = active & (s2 > 0) & (np.abs(gam) < 100.0) & (aa_prev_fac == n_factor_at_step) & (n_factor_at_step <= 8)
+                    okg = active & (s2 > 0) & (np.abs(gam) < 100.0) & (aa_prev_fac == n_factor_at_step) & (n_factor_at_step <= (16 if (aa_x_only and P.h > 20) else 8))
                     gam = np.where(okg, gam, 0.0).astype(rdt)
                     n1, n2 = x.size // B, z.size // B
                     x = x - gam[:, None, None, None] * aa_g[:, :n1].reshape(x.shape).astype(rdt)

@@ -750,7 +750,10 @@ def test_stage_path_golden_batches(name):
     assert (info["status"] == 0).all(), info["status"]
     assert e.max() <= util.REL_TOL and es.max() <= util.REL_TOL
     if h <= 20:
-        dense, _ = _solver(h, half, path=PATH_DENSE, accel=0)     # (the dense family's secant extrapolation off: the shared method)
+        # the plain method (secant extrapolation off: it amplifies last-bit differences into different paths) on both families
+        plain, _ = _solver(h, half, path=PATH_STAGE, accel=0)
+        _, _, info = plain.solve(d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"], mu=mu)
+        dense, _ = _solver(h, half, path=PATH_DENSE, accel=0)
         assert dense._lib.bmpc_solver_path(dense._h) == PATH_DENSE
         _, _, info_d = dense.solve(d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"], mu=mu)
         assert np.abs(info["iters"].astype(int) - info_d["iters"]).max() <= 10          # (f32 preconditioners differ in the last bits)
@@ -1053,26 +1056,29 @@ def test_runs_are_bitwise_reproducible(h, path, B):
     sol.close()
 
 
-@pytest.mark.parametrize("h,gait,seed,kw", [(10, "standing", 1, {}), (10, "mixed", 3, dict(vx_cmd=True)),
-                                             (20, "walking", 4, dict(vx_cmd=True, per_step_mu=True))])
-def test_secant_extrapolation_saves_iterations_and_keeps_the_fixed_point(h, gait, seed, kw):
-    """bmpc_params.accel (default on, dense family): at a stopping test the iterate is extrapolated along its last state
+@pytest.mark.parametrize("h,gait,seed,kw,path,gain", [(10, "standing", 1, {}, PATH_DENSE, 0.97), (10, "mixed", 3, dict(vx_cmd=True), PATH_DENSE, 0.97),
+                                                       (20, "walking", 4, dict(vx_cmd=True, per_step_mu=True), PATH_DENSE, 0.97),
+                                                       (10, "mixed", 3, dict(vx_cmd=True), PATH_STAGE, 0.97),
+                                                       (32, "walking", 5, dict(vx_cmd=True, per_step_mu=True), PATH_STAGE, 0.99)])
+def test_secant_extrapolation_saves_iterations_and_keeps_the_fixed_point(h, gait, seed, kw, path, gain):
+    """bmpc_params.accel (default on; both families -- the stage family with the x part of the state as the secant's metric): at a stopping test the iterate is extrapolated along its last state
     change, w <- T(w) - gamma (T(w) - w) with gamma from the last two changes (Anderson acceleration, memory one).  It is a
     different path to the SAME fixed point: every instance converges, the controls agree with the plain run to the
-    solver's tolerance, and a batch needs >= 3 % fewer iterations and no more factorisations (model and GPU: ~ -6 %)."""
+    solver's tolerance, and a batch needs >= 3 % fewer iterations (1 % at the long horizons, which re-classify twice as often)
+    and no more factorisations (model and GPU: ~ -6 % at h = 10 .. 20)."""
     import biped_mpc_py_amd as bm
-    B = 4096
+    B = 4096 if h <= 20 else 2048
     s = util.synth_batch(B, h, seed, gait=gait, **kw)
     out = {}
     for acc in (0, 1):
         mpc = bm.MPC()
         mpc.h = h
-        sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(path=PATH_DENSE, accel=acc))
+        sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(path=path, accel=acc))
         _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
         sol.close()
         assert int((info["status"] != 0).sum()) == 0
         out[acc] = (u, info["iters"].mean(), info["nfactor"].mean(), info["iters"].max())
     print("h=%d %s: iterations %.1f -> %.1f, factorisations %.2f -> %.2f, worst %d -> %d" % (
         h, gait, out[0][1], out[1][1], out[0][2], out[1][2], out[0][3], out[1][3]))
-    assert out[1][1] <= 0.97 * out[0][1] and out[1][2] <= out[0][2]
+    assert out[1][1] <= gain * out[0][1] and out[1][2] <= out[0][2]
     assert util.rel_err(out[1][0], out[0][0]).max() <= util.REL_TOL
