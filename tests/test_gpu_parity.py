@@ -938,8 +938,12 @@ def test_bench_two_ranks_on_one_device_over_rccl_fails_cleanly():
     assert not any(ln.startswith("{") for ln in p.stdout.decode("utf-8", "replace").splitlines())
     import psutil
     me = os.getpid()
-    left = [q for q in psutil.process_iter(["pid", "cmdline", "ppid"])
-            if q.info["pid"] != me and q.info["cmdline"] and any("bench.py" in a for a in q.info["cmdline"])]
+    # (a Python process running bench.py as its script -- not a shell whose command line merely mentions it, and not an
+    #  ancestor of this test, e.g. a wrapper that runs the test suite and the bench in one command)
+    ancestors = {q.pid for q in psutil.Process(me).parents()}
+    left = [q for q in psutil.process_iter(["pid", "cmdline", "ppid", "name"])
+            if q.info["pid"] != me and q.info["pid"] not in ancestors and q.info["cmdline"]
+            and "python" in (q.info["name"] or "") and any(a.endswith("bench.py") for a in q.info["cmdline"][1:3])]
     assert not left, [(q.info["pid"], q.info["cmdline"]) for q in left]
     # and the GPU still works for this process
     assert float(torch.ones(4, device="cuda").sum().item()) == 4.0
