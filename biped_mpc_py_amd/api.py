@@ -130,12 +130,15 @@ class BatchSolver:
         info = dict(iters=iters, status=status, nfactor=nfactor, residuals=resid)
         return (None if states is None else states.astype(np.float64)), controls.astype(np.float64), info
 
-    def assemble(self, x_fb, foot, contact, phase, x_cmd=None, mu=None):
-        """Assembly stage only (parity tests): x_ref (B,h,12), foot_ref (B,h,6), Gt (B,6h,6h), qt (B,6h)."""
+    def assemble(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_matrices=True):
+        """Assembly stage only (parity tests, reference generators): x_ref (B,h,12), foot_ref (B,h,6) and -- with
+        `want_matrices`, dense family only (h <= 20) -- Gt (B,6h,6h), qt (B,6h), else None for both.  Without them the
+        launch runs on the handle's own kernel family at every supported horizon and nothing of size (6h)^2 is allocated."""
         B, x_fb, foot, contact, phase, x_cmd, mu = self._marshal(x_fb, foot, contact, phase, x_cmd, mu)
         h = self.h
         x_ref = np.zeros((B, h, 12)); foot_ref = np.zeros((B, h, 6))
-        Gt = np.zeros((B, 6 * h, 6 * h)); qt = np.zeros((B, 6 * h))
+        Gt = np.zeros((B, 6 * h, 6 * h)) if want_matrices else None
+        qt = np.zeros((B, 6 * h)) if want_matrices else None
         _lib.check(self._lib.bmpc_debug_assemble(
             self._h, B, _ptr(x_fb), _ptr(foot), _ptr(contact), _ptr(phase), _ptr(x_cmd), _ptr(mu),
             _ptr(x_ref), _ptr(foot_ref), _ptr(Gt), _ptr(qt)))
@@ -396,7 +399,7 @@ def reference_trajectories_batch(x_fb, t, foot, contact, mpc=None, biped=None, x
     x_fb = np.asarray(x_fb, float).reshape(-1, 12)
     if phase is None:
         phase = phase_indices(t, mpc.dt, mpc.h)
-    x_ref, foot_ref, _, _ = solver.assemble(x_fb, foot, contact, phase, x_cmd=x_cmd)
+    x_ref, foot_ref, _, _ = solver.assemble(x_fb, foot, contact, phase, x_cmd=x_cmd, want_matrices=False)
     B, h = x_ref.shape[0], x_ref.shape[1]
     xr = np.concatenate([x_ref.transpose(0, 2, 1), np.ones((B, 1, h))], axis=1)       # REF:62: 13th row of ones
     return xr, foot_ref.transpose(0, 2, 1)

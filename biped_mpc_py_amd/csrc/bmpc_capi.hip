@@ -139,9 +139,10 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     bmpc_params ref;
     bmpc_default_params(&ref, p.h <= 20 ? p.h : 10);
     const CurvScales c0 = curvature_scales(ref), c1 = curvature_scales(p);
-    if (c0.force > 0 && c0.moment > 0 && c0.soft > 0 && c1.force > 0 && c1.moment > 0 && c1.soft > 0) {
-      pf = c1.force / c0.force; pm = c1.moment / c0.moment; pr = c1.soft / c0.soft;
-    }
+    if (!(c1.force > 0 && c1.moment > 0 && c1.soft > 0))
+      return fail(BMPC_ERR_INVALID, "penalty_mode SCALED needs positive curvature scales (force %g, moment %g, soft %g: some "
+                  "tracking weight Q is zero on every state a control acts on); use BMPC_PENALTY_ABSOLUTE", c1.force, c1.moment, c1.soft);
+    pf = c1.force / c0.force; pm = c1.moment / c0.moment; pr = c1.soft / c0.soft;
   } else if (p.penalty_mode != BMPC_PENALTY_ABSOLUTE) {
     return fail(BMPC_ERR_INVALID, "unknown penalty_mode %d", p.penalty_mode);
   }
@@ -570,7 +571,12 @@ int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* fo
   HIP_TRY(h->phase.ensure(n)); HIP_TRY(h->controls.ensure(n * H * 12));
   if (x_cmd) HIP_TRY(h->x_cmd.ensure(n * 12));
   if (mu) HIP_TRY(h->mu.ensure(n * H * 2));
-  const size_t o_xr = 0, o_fr = o_xr + n * H * 12, o_gt = o_fr + n * H * 6, o_qt = o_gt + n * NW * NW, tot = o_qt + n * NW;
+  // only what the caller asked for is formed: Gt alone is n (6h)^2 doubles (1.9 GB at B = 4096, h = 40), and the Gt / qt
+  // views exist on the dense family only (h <= 20) -- a caller that wants the references gets them at every horizon
+  if ((Gt || qt) && !dense_horizon(h->dev.h))
+    return fail(BMPC_ERR_INVALID, "Gt / qt views exist for h <= 20 only (h=%d never forms them); pass NULL for both", h->dev.h);
+  const size_t o_xr = 0, o_fr = o_xr + n * H * 12, o_gt = o_fr + n * H * 6, o_qt = o_gt + (Gt ? n * NW * NW : 0),
+               tot = o_qt + (qt ? n * NW : 0);
   HIP_TRY(h->dbg.ensure(tot));
   hipStream_t st = h->stream;
   HIP_TRY(hipMemsetAsync(h->dbg.p, 0, tot * sizeof(double), st));
@@ -580,7 +586,7 @@ int bmpc_debug_assemble(bmpc_handle h, int B, const float* x_fb, const float* fo
   HIP_TRY(hipMemcpyAsync(h->phase.p, phase, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
   if (x_cmd) HIP_TRY(hipMemcpyAsync(h->x_cmd.p, x_cmd, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
   if (mu) HIP_TRY(hipMemcpyAsync(h->mu.p, mu, n * H * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-  bmpc::DebugOut dbg = {h->dbg.p + o_xr, h->dbg.p + o_fr, h->dbg.p + o_gt, h->dbg.p + o_qt, nullptr, 1};
+  bmpc::DebugOut dbg = {h->dbg.p + o_xr, h->dbg.p + o_fr, Gt ? h->dbg.p + o_gt : nullptr, qt ? h->dbg.p + o_qt : nullptr, nullptr, 1};
   rc = launch(h, B, h->x_fb.p, h->foot.p, h->contact.p, h->phase.p, x_cmd ? h->x_cmd.p : nullptr,
               mu ? h->mu.p : nullptr, h->controls.p, nullptr, nullptr, nullptr, nullptr, nullptr, dbg, st, nullptr);
   if (rc != BMPC_OK) return rc;

@@ -145,7 +145,7 @@ struct alignas(16) StageSmem {
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
-  float red[2][8][NW];         // reductions across the waves (six maxima, two sums)
+  float red[2][11][NW];        // reductions across the waves (nine maxima, two sums)
   // block-diagonal part of K^-1 (see bmpc_kernels.hip): L~ = L E^-1 (acceleration space), Kn = {Ka^-1, T Ka^-1}.
   // (no G images as in the dense kernels: an instance's LDS decides how many instances share a CU, and the step d
   //  is exchanged once per iteration instead)
@@ -1407,6 +1407,7 @@ stage_body(const DevParams& P, const int B,
     };
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f, slw = 0.f;
+    float r0 = 0.f, nx0 = 0.f, slw0 = 0.f;       // the rows of step 0 alone: the applied control has its own stopping test (bmpc_kernels.hip)
     const bool check_now = (it + 1 == next_check) || (it + 1 == P.max_iter);     // wave-uniform
     float dstep[NP];                          // d_f[c] = (null-space part) + L~ a
 #pragma unroll
@@ -1486,6 +1487,13 @@ stage_body(const DevParams& P, const int B,
           rs = fmaxf(rs, fabsf((float)(xto - xo[s])));
           // a NaN iterate must reach the test (fmaxf drops NaNs): it is reported as an infinite norm
           nx = fmaxf(nx, (xto == xto) ? fabsf((float)xto) : __builtin_inff());
+          if (s == 0 && js[0] == 0) {             // (s is a constant of the unrolled pass: only the first slot can be step 0)
+            r0 = fmaxf(fmaxf(fabsf((float)st_pb), fabsf((float)st_pg)), fabsf((float)(xto - xo[s])));
+            nx0 = fabsf((float)xto);
+            const bool actb = (znb <= (RT)lb[s] || znb >= (RT)ub[s]) && ybn != (RT)0;
+            const bool actg = (zng >= (RT)0) && ygn != (RT)0;
+            slw0 = fmaxf((actb || eqb[s]) ? 0.f : rvb[s] * fabsf((float)st_pb), actg ? 0.f : rvg[s] * fabsf((float)st_pg));
+          }
         }
       }
       if constexpr (MODE == 1) {
@@ -1558,10 +1566,12 @@ stage_body(const DevParams& P, const int B,
       }
       // (see bmpc_kernels.hip: the third stopping test -- the pull rho |z~ - z| of the inactive rows against the softest
       //  curvature; an instance that fails it re-classifies at once instead of stopping)
-      constexpr float SLOW_TOL = 1.0e-5f;
-      float v5[8] = {rp, rs, nz, nx, chg, slw, aa1, aa2};
+      constexpr float SLOW_TOL = 1.0e-6f;
+      float v5[11] = {rp, rs, nz, nx, chg, slw, aa1, aa2, r0, nx0, slw0};
 #pragma unroll
       for (int k = 0; k < 6; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
+#pragma unroll
+      for (int k = 8; k < 11; ++k) v5[k] = __uint_as_float(row0_umax(__float_as_uint(v5[k])));   // (step 0: lanes 0 .. 11 of wave 0)
       if (two_pass) {                           // (uniform) the two secant sums ride in the same exchange
         v5[6] = wave_sum(v5[6]);
         v5[7] = wave_sum(v5[7]);
@@ -1571,11 +1581,12 @@ stage_body(const DevParams& P, const int B,
         ++n_red;
         if (l == 0) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) red[k][wv] = v5[k];
+          for (int k = 0; k < 11; ++k) red[k][wv] = v5[k];
         }
         sync_workgroup();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 11; ++k) {
+          if (k == 6 || k == 7) continue;
           unsigned m = __float_as_uint(red[k][0]);
 #pragma unroll
           for (int w2 = 1; w2 < NW; ++w2) { const unsigned o = __float_as_uint(red[k][w2]); m = m > o ? m : o; }
@@ -1594,9 +1605,16 @@ stage_body(const DevParams& P, const int B,
         res_s = v5[1];
         const float tol_p = P.eps_pri * fmaxf(1.f, v5[2]), tol_s = P.eps_dua * fmaxf(1.f, v5[3]);
         const bool bad = !(v5[0] == v5[0]) || !(v5[1] == v5[1]) || !(v5[3] < 3.0e38f);
-        const bool small = v5[0] <= tol_p && v5[1] <= tol_s;
-        const bool done = small && !(v5[5] > SLOW_TOL * P.r2min * fmaxf(1.f, v5[3]));
-        force_adapt = small && !done && !bad && nfac <= P.max_refactor && it < P.max_iter;
+        // (the rows of step 0 -- the applied control, REF:493 -- are also held to U0_TOL x eps relative to their own norm:
+        //  bmpc_kernels.hip)
+        constexpr float U0_TOL = 5.f;
+        const float n0 = fmaxf(1.f, v5[9]);
+        const bool small = v5[0] <= tol_p && v5[1] <= tol_s && v5[8] <= U0_TOL * fmaxf(P.eps_pri, P.eps_dua) * n0;
+        // (an instance that may not re-classify any more -- budget of factorisations spent, adaptation switched off -- is
+        //  taken as it is: the third test can only be answered by a re-classification)
+        const bool can_adapt = nfac <= P.max_refactor && P.adapt_every > 0;
+        const bool done = small && (!(v5[5] > SLOW_TOL * P.r2min * fmaxf(1.f, v5[3]) || v5[10] > U0_TOL * SLOW_TOL * P.r2min * n0) || !can_adapt);
+        force_adapt = small && !done && !bad && it < P.max_iter;
         const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
         next_check += far ? 2 * check_every : check_every;
         if (two_pass) {                         // the commit of this iteration's update, along the secant where the instance goes on

@@ -61,9 +61,21 @@ def kernel_source_hash():
     import os
     import re
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hsh = hashlib.sha256()
-    for name in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip"):
-        with open(os.path.join(here, name), "r", encoding="utf-8") as fh:
+    # everything that decides the code object and the parameter block it runs with: the four sources, the C ABI header
+    # (DevParams / bmpc_params layout, defaults) and the compile flags of __graft_entry__.build()
+    try:
+        import __graft_entry__ as _ge
+        flags = " ".join(_ge.KERNEL_FLAGS)
+    except Exception:                       # (package used outside the repository: the sources alone)
+        flags = ""
+    hsh.update(flags.encode())
+    for path in [os.path.join(here, n) for n in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip", "bmpc_lowlevel.hip")] + \
+                [os.path.join(root, "include", "bmpc.h")]:
+        if not os.path.exists(path):
+            continue
+        with open(path, "r", encoding="utf-8") as fh:
             text = fh.read()
         # (no string literal of these files holds "//" or "/*": checked by tests/test_host_logic.py)
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)

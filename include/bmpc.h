@@ -60,7 +60,11 @@ enum bmpc_rescue_mode {
 /* per-instance status[] values written by the solver */
 enum bmpc_instance_status {
   BMPC_SOLVED = 0,           /* stopping criteria met */
-  BMPC_MAX_ITER = 1,         /* iteration cap reached (result is the last iterate) */
+  BMPC_MAX_ITER = 1,         /* iteration cap reached (result is the last iterate).  The stopping criteria are three: the
+                                primal and the step residual within eps_pri / eps_dua, and no inactive row still pulling
+                                (penalty x |z~ - z| <= 1e-5 x 2 min R x max(1, |x|)); an instance that fails only the third
+                                re-classifies at once, and one that can no longer re-classify (max_refactor spent, or
+                                adapt_every = 0) is accepted on the first two alone -- it is never held to the cap by it */
   BMPC_NUMERICAL = 2         /* NaN/Inf encountered */
 };
 
@@ -109,9 +113,15 @@ typedef struct bmpc_params {
                                 6h x 6h inverse in registers; h <= 20) or BMPC_PATH_STAGE (stage-structured Riccati solve,
                                 O(h) work and state; every supported h).  Same optimum, same outer method. */
   int32_t penalty_mode;      /* BMPC_PENALTY_SCALED (default): rho, rho_lo, rho_hi_*, rho_eq are the values at the reference
-                                problem (REF:22-48 defaults, h = 10) and are scaled by the curvature of the problem at
-                                hand relative to it -- stiff end (Q, dt, m, I, h) for the ceilings and rho_eq, 2 R for the
-                                floor, their geometric mean for the start; BMPC_PENALTY_ABSOLUTE: taken as they are */
+                                problem -- REF:22-48 defaults at THIS problem's horizon for h <= 20 (so a fixed model shows
+                                no horizon scaling between h = 8 and h = 20: the absolute values were tuned and soaked
+                                there), at h = 10 for h > 20 (the stiff end then grows like sum k^2 ~ h^3) -- and are
+                                scaled by the curvature of the problem at hand relative to it: stiff end (Q, dt, m, I, h)
+                                for the ceilings and rho_eq, 2 R for the floor, their geometric mean for the start.  The
+                                ceilings and rho_eq are capped at 1e6 (2 min R + rho_lo), what the f32 factors hold.
+                                Degenerate curvature scales (every Q of a state group zero) are BMPC_ERR_INVALID, not a
+                                silent fallback.  BMPC_PENALTY_ABSOLUTE: the fields are taken as they are.
+                                bmpc_effective_penalties() returns what a block resolves to. */
   int32_t rescue;            /* BMPC_RESCUE_AUTO (default), _OFF, _ON: after a solve on the dense family, the instances whose
                                 status is not 0 are solved again by the stage family (one more launch on the same stream,
                                 its workgroups leave at once where the status is 0; the outputs of a rescued instance,

@@ -102,6 +102,16 @@ static inline unsigned wave_umax(unsigned v) {          // maximum over the lane
   wb.arrive_and_wait();
   return m;
 }
+static inline unsigned row0_umax(unsigned v) {          // maximum over lanes 0 .. 15 of the lane's wave, to every lane of it
+  std::barrier<>& wb = *g_wbar[threadIdx.x >> 6];
+  g_red[threadIdx.x] = v;
+  wb.arrive_and_wait();
+  unsigned m = 0;
+  const int w0 = threadIdx.x & ~63;
+  for (int i = 0; i < 16; ++i) m = g_red[w0 + i] > m ? g_red[w0 + i] : m;
+  wb.arrive_and_wait();
+  return m;
+}
 // sum over the lane's wave in the order of the GPU's DPP tree (bmpc_kernels.hip wave_sum): inclusive scan inside rows of
 // 16 by shifts 1, 2, 4, 8 (zero where the source lane is outside the row), then row 1 += lane 15, rows 2, 3 += lane 31
 static float g_redf[1024];

@@ -9,6 +9,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
+PATH_AUTO, PATH_DENSE, PATH_STAGE = 0, 1, 2
+
+
 def _solver(h, half, **opts):
     import biped_mpc_py_amd as bm
     mpc = bm.MPC()
@@ -536,6 +539,39 @@ def test_bench_two_ranks_strong_scaling():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["total"] == 4099
     assert "bit-identical" in line["config"]["gather_check"]
     assert line["config"]["not_converged"] == 0
+    assert line["ranks"]["world_size_backend"] == 2 and line["ranks"]["backend"] == "gloo" and len(line["ranks"]["devices"]) == 2
+
+
+def test_bench_bare_n_gpus_reports_the_north_star_partition_and_proves_its_rank_count():
+    """What the driver runs at N > 1 -- bare `bench.py --gpus N --steps K --warmup W`, nothing else -- must carry, on ONE
+    line: `value` = the weak-scaling number (N = 1 equals BENCH), a `strong` record = the north_star partition (ONE batch of
+    config 4 sharded over the ranks, broadcast + solve + all_gather per step, gathered controls bit-identical to the
+    single-GPU solve, solves/s), and in `ranks` the world size the PROCESS GROUP reports after init_process_group together
+    with one device identity per rank.  Two ranks on this box's one GPU, so over gloo (`--backend gloo --share-device` are
+    rehearsal flags; the driver's run uses nccl = RCCL and one GPU per rank); `--total` only shrinks the batch of the record."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--total", "8193", "--backend", "gloo", "--share-device"], env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([x for x in p.stdout.decode().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["baseline_config"] == 2
+    assert line["config"]["total"] == 2 * 4096 and line["config"]["collectives_in_step"] == ["all_gather(controls)"]
+    sr = line["strong"]
+    assert sr["baseline_config"] == 4 and sr["total"] == 8193 and sr["scaling"] == "strong" and sr["value"] > 0
+    assert sr["collectives_in_step"] == ["broadcast(params)", "all_gather(controls)"]
+    assert "bit-identical" in sr["gather_check"] and sr["not_converged_rank0"] == 0 and len(sr["kernel_ms_per_rank"]) == 2
+    rk = line["ranks"]
+    assert rk["world_size_backend"] == 2 and rk["backend"] == "gloo" and len(rk["devices"]) == 2
+    assert all(d.startswith("rank %d:" % i) and "uuid" in d for i, d in enumerate(rk["devices"]))
+    assert rk["distinct_devices"] == 1                     # (both ranks of this rehearsal sit on the one GPU)
+    # the contract's roofline keys: `frac` is the SURVEY 8(d) number again, `frac_survey_formula` the same under the stable key
+    rf = line["roofline"]
+    assert abs(rf["frac"] - rf["frac_survey_formula"]) < 1e-12 and rf["frac_executed"] < rf["frac"]
 
 
 @pytest.mark.parametrize("gait", ["standing", "walking"])
@@ -606,6 +642,45 @@ def test_reference_generators_dropin():
     d = util.load("cfg4_walking_h10")
     xr, fr = bm.reference_trajectories_batch(d["x_fb"], d["t"], d["foot"], d["contact"], mpc=mpc, x_cmd=d["x_cmd"])
     assert np.abs(xr - d["x_ref"]).max() < 1e-6 and np.abs(fr - d["foot_ref"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("h,path", [(10, PATH_STAGE), (16, PATH_STAGE), (32, PATH_AUTO), (40, PATH_AUTO)])
+def test_reference_generators_at_every_horizon_and_on_the_stage_family(h, path):
+    """`assemble` / `reference_trajectories_batch` (REF:61-109 on the device) at the horizons only the stage family solves,
+    and through the stage kernel's own reference branch at h <= 20 (path = STAGE), against the oracle's generators with the
+    same half period.  (Round 3 always asked for the Gt / qt views, which exist for h <= 20 only: the call failed beyond,
+    and at h <= 20 it silently ran the dense kernel whatever the path.)  The views themselves are refused beyond h = 20."""
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd._lib import BmpcError
+    from oracle import bmpc_oracle as orc
+    B = 48
+    s = util.synth_batch(B, h, 40 + h, gait="walking", vx_cmd=True)
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(path=path))
+    assert sol._lib.bmpc_solver_path(sol._h) == PATH_STAGE
+    x_ref, foot_ref, Gt, qt = sol.assemble(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], want_matrices=False)
+    assert Gt is None and qt is None
+    om = orc.MPC()
+    om.h = h
+    for i in range(B):
+        om.x_cmd = s["x_cmd"][i].astype(np.float32).astype(float)
+        xf, ft = s["x_fb"][i].astype(np.float32).astype(float), s["foot"][i].astype(np.float32).astype(float)
+        xr = orc.get_reference_trajectory(xf, om)
+        fr = orc.get_reference_foot_trajectory(xf, (s["phase"][i] + 0.5) * om.dt, ft, om, s["contact"][i], half=s["half"])
+        assert np.abs(x_ref[i].T - xr[:12]).max() < 1e-6 and np.abs(foot_ref[i].T - fr).max() < 1e-6, i
+    if h > 20:
+        with pytest.raises(BmpcError):
+            sol.assemble(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], want_matrices=True)
+    else:                                       # the views of the dense family, whatever the handle's path
+        _, _, Gt, qt = sol.assemble(s["x_fb"][:2], s["foot"][:2], s["contact"][:2], s["phase"][:2], x_cmd=s["x_cmd"][:2])
+        assert Gt.shape == (2, 6 * h, 6 * h) and np.abs(Gt - Gt.transpose(0, 2, 1)).max() <= 1e-9 * np.abs(Gt).max()
+    sol.close()
+    # the drop-in wrappers (one instance, the handle cache) at a long horizon
+    bm.close_cached_solvers()
+    xr1 = bm.get_reference_trajectory(s["x_fb"][0], mpc)
+    assert xr1.shape == (13, h) and np.abs(xr1[:12, 0] - s["x_fb"][0].astype(np.float32)).max() < 1e-6
+    bm.close_cached_solvers()
 
 
 @pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 2048), (5, 2048)])
@@ -711,7 +786,6 @@ def test_rollout_longest_first_dispatch_same_results_less_time():
 # ------------------------------------------------------------------------------------------------------------------
 # the stage-structured kernel family (bmpc_stage.hip), the horizon as a launch parameter
 # ------------------------------------------------------------------------------------------------------------------
-PATH_DENSE, PATH_STAGE = 1, 2
 
 
 def _hgen(h):
@@ -953,38 +1027,60 @@ def _oracle_worker(a):
     from threadpoolctl import threadpool_limits
     from oracle import bmpc_oracle as orc
     with threadpool_limits(limits=1):
-        x, f, c = a
-        _, ct, info = orc.solve_mpc(x, 0.02, f, orc.MPC(), orc.Biped(), c, return_info=True)
+        x, f, c, xc, mu, h, half, ph = a
+        mpc = orc.MPC()
+        mpc.h = h
+        mpc.x_cmd = xc
+        _, ct, info = orc.solve_mpc(x, (ph + 0.5) * mpc.dt, f, mpc, orc.Biped(), c, half=half, mu_steps=mu, return_info=True)
         k = info["kkt"]
         return ct, bool(info["polished"]) and max(k["stationarity"], k["primal_ineq"], k["complementarity"]) <= 1e-7
 
 
-def test_parity_against_the_oracle_at_scale():
-    """8192 instances of the headline shape against the certified oracle, EVERY instance, on both kernel families (the
-    fixtures hold 64).  This batch contains the two instances that used to stop early on small residuals (an inactive
-    row still far above the penalty floor: 2.5e-4 and 9.8e-5 from the optimum on either family) -- the third stopping
-    test (pull of the inactive rows) holds them to the optimum now."""
+# every BASELINE shape, instance by instance: (label, B, h, gait, seed, generator options)
+_AT_SCALE = [("config2_standing_h10", 8192, 10, "standing", 31, {}),
+             ("config4_mixed_h10", 8192, 10, "mixed", 3, dict(vx_cmd=True)),
+             ("config3_trot_h16", 4096, 16, "walking", 2, dict(vx_cmd=True)),
+             ("config5_mu_h20", 4096, 20, "walking", 4, dict(vx_cmd=True, per_step_mu=True))]
+
+
+@pytest.mark.parametrize("label,B,h,gait,seed,kw", _AT_SCALE, ids=[a[0] for a in _AT_SCALE])
+def test_parity_against_the_oracle_at_scale(label, B, h, gait, seed, kw):
+    """EVERY instance of a batch of every BASELINE config shape (2: standing, 4: mixed gaits, 3: h = 16 trot, 5: h = 20 with
+    per-step friction) against the certified fp64 oracle on the fp32-rounded inputs the GPU sees, on both kernel families,
+    on both metrics of SURVEY 8(d): all h x 12 controls, and the row the reference applies (`u0`, REF:493).  (The fixtures
+    hold 16..64 instances per shape; a 1-in-10^4 failure only shows here.  The standing batch contains the two instances
+    that used to stop early on small residuals, fixed by the third stopping test.)  Round 4: the dense family forms its
+    gradient in state space like the stage family (no f32 copy of the Hessian in the fixed point) -- before that it sat at
+    4e-5 on config 2 and, on the u0 metric, OUTSIDE the tolerance on single instances of configs 3 and 5 (1.0e-4, 6.2e-4 in
+    512).  The log of this test is kept as profiles/r04_parity_at_scale.txt."""
     import multiprocessing as mp
     import os
     import biped_mpc_py_amd as bm
-    B = 8192
-    s = util.synth_batch(B, 10, 31, gait="standing")
-    args = [(s["x_fb"][i].astype(np.float32).astype(float), s["foot"][i].astype(np.float32).astype(float), s["contact"][i]) for i in range(B)]
+    s = util.synth_batch(B, h, seed, gait=gait, **kw)
+    r32 = lambda v: v.astype(np.float32).astype(float)
+    args = [(r32(s["x_fb"][i]), r32(s["foot"][i]), s["contact"][i], r32(s["x_cmd"][i]),
+             None if s["mu"] is None else r32(s["mu"][i]), h, s["half"], int(s["phase"][i])) for i in range(B)]
     with mp.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:
-        res = pool.map(_oracle_worker, args, chunksize=32)
+        res = pool.map(_oracle_worker, args, chunksize=16)
     ref = np.stack([r[0] for r in res])
     ok = np.array([r[1] for r in res])
     assert ok.mean() > 0.999                                    # (an uncertified reference is no yardstick)
+    mpc = bm.MPC()
+    mpc.h = h
     for path in (PATH_DENSE, PATH_STAGE):
-        sol = bm.BatchSolver(max_batch=B, solver_options=dict(path=path))
-        _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], want_states=False)
+        sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(path=path))
+        _, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
         sol.close()
-        e = util.rel_err(u, ref)[ok]
-        print("path %d: max rel err %.2e p99.9 %.2e, above 5e-5: %d; the two former early stops: %.2e %.2e" % (
-            path, e.max(), np.quantile(e, 0.999), int((e > 5e-5).sum()), util.rel_err(u[7055][None], ref[7055][None])[0],
-            util.rel_err(u[7074][None], ref[7074][None])[0]))
+        e, e0 = util.rel_err(u, ref)[ok], util.u0_err(u, ref)[ok]
+        print("%s path %s (%d of %d references certified): all controls max %.2e p99.9 %.2e above 5e-5: %d | u0 max %.2e p99.9 %.2e "
+              "above 5e-5: %d | iterations %.1f (max %d), not converged %d" % (
+                  label, "dense" if path == PATH_DENSE else "stage", int(ok.sum()), B, e.max(), np.quantile(e, 0.999), int((e > 5e-5).sum()),
+                  e0.max(), np.quantile(e0, 0.999), int((e0 > 5e-5).sum()), info["iters"].mean(), info["iters"].max(),
+                  int((info["status"] != 0).sum())))
         assert (info["status"] == 0).all()
-        assert e.max() <= (5e-5 if path == PATH_DENSE else 5e-6)
+        assert e.max() <= util.REL_TOL and e0.max() <= util.REL_TOL
+        # regression bounds well inside the tolerance (measured on MI355X: profiles/r04_parity_at_scale.txt)
+        assert e.max() <= 1e-5 and e0.max() <= 2e-5, (e.max(), e0.max())
 
 
 def test_rescue_pass_recovers_what_the_dense_sweep_loses():

@@ -179,8 +179,18 @@ def test_kernel_source_hash_covers_code_not_commentary():
     import re
     from biped_mpc_py_amd.synth import kernel_source_hash
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "biped_mpc_py_amd", "csrc")
-    for name in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip"):
+    for name in ("bmpc_kernels.hip", "bmpc_stage.hip", "bmpc_capi.hip", "bmpc_lowlevel.hip", os.path.join("..", "..", "include", "bmpc.h")):
         text = open(os.path.join(here, name), encoding="utf-8").read()
         for m in re.finditer(r'"([^"\n]*)"', text):
             assert "//" not in m.group(1) and "/*" not in m.group(1), (name, m.group(0))
     assert re.fullmatch(r"[0-9a-f]{16}", kernel_source_hash())
+    # the hash covers everything that decides the code object: the compile flags are part of it
+    import __graft_entry__ as ge
+    h0 = kernel_source_hash()
+    saved = list(ge.KERNEL_FLAGS)
+    try:
+        ge.KERNEL_FLAGS.append("-DSOMETHING")
+        assert kernel_source_hash() != h0
+    finally:
+        ge.KERNEL_FLAGS[:] = saved
+    assert kernel_source_hash() == h0

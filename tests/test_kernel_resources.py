@@ -35,12 +35,14 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
                                      if k != "offset" and k != "size"}
     assert sorted(seen) == [8, 10, 12, 14, 16, 18, 20], seen
     for h, meta in seen.items():
-        # everything in registers up to h = 16; the two longest dense horizons (54 / 60 floats of a row half next to the f64
-        # state) are allowed a handful of spilled registers -- set-up values stored once and reloaded at the stopping tests
-        # and the outputs (h = 20: 4 since the secant extrapolation; measured with it: -5.7 % kernel time)
-        assert int(meta["vgpr_spill_count"]) <= (0 if h in (8, 10, 12, 14, 16) else 4), (h, meta)
-        if h not in (18, 20):
+        # everything in registers up to h = 14; the long dense horizons (48 .. 60 floats of a row half next to the f64 state)
+        # are allowed spilled registers -- set-up values stored ONCE and reloaded at the stopping tests (the exact rebuild of
+        # the gradient in state space, round 4: ~25 transient registers at the point where the whole loop state is live)
+        # and at the outputs; test_no_scratch_access_in_the_hot_loops below holds that none is touched per iteration
+        assert int(meta["vgpr_spill_count"]) <= {8: 0, 10: 0, 12: 0, 14: 0, 16: 8, 18: 24, 20: 24}[h], (h, meta)
+        if h <= 14:
             assert int(meta["private_segment_fixed_size"]) == 0, (h, meta)       # no scratch
+        assert int(meta["private_segment_fixed_size"]) <= 128, (h, meta)
         assert int(meta["vgpr_count"]) + meta["agpr_count"] <= 256, (h, meta)      # two waves per SIMD
         lds = int(meta["group_segment_fixed_size"])
         waves = (12 * h + 63) // 64 if h % 5 else 2 * (h // 5) * 64 // 64
@@ -61,6 +63,44 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
         assert 160 * 1024 // lds >= 2, (n_p, n_w, lds)              # at least two instances per CU at h = 40
         assert int(meta["vgpr_spill_count"]) == 0 and int(meta["private_segment_fixed_size"]) == 0, (n_p, n_w, meta)
         assert int(meta["vgpr_count"]) <= 512, (n_p, n_w, meta)          # (unified register file: the count includes the AGPRs)
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
+def test_no_scratch_access_in_the_hot_loops(isa_text):
+    """Where a dense kernel spills (h >= 16), the spilled values are stored during the set-up and reloaded in code that
+    runs at stopping tests / on the way out only: no scratch instruction sits in the body of the sweep loop or of the ADMM
+    iteration.  Both hot bodies are recognisable in the ISA by their packed FMAs: the code between the first and the last
+    `v_pk_fma_f32` of a kernel spans the sweep loop and the iteration's phases P0-P5 (mat-vec and gradient increment);
+    the stopping test, the rebuild and the outputs follow the last one.  Scratch STORES in between are allowed only before
+    the sweep (set-up / factor prologue executed once per factorisation); LOADS are not allowed inside the sweep loop, and at
+    most the factor prologue's (one per factorisation) before the iteration phases."""
+    lines = isa_text.splitlines()
+    seen = 0
+    for i, ln in enumerate(lines):
+        m = re.match(r"_ZN4bmpc\d+solve_kernelILi(\d+)EE\S*:", ln)
+        if not m:
+            continue
+        seen += 1
+        end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        body = [x.split(";")[0].strip() for x in lines[i + 1:end]]
+        pk = [k for k, x in enumerate(body) if x.startswith("v_pk_fma_f32")]
+        bars = [k for k, x in enumerate(body) if x.startswith("s_barrier")]
+        # the sweep loop: the backward branch that encloses the densest run of packed FMAs
+        labels = {mm.group(1): k for k, x in enumerate(body) for mm in [re.match(r"(\.LBB\d+_\d+):", x)] if mm}
+        loops = []
+        for k, x in enumerate(body):
+            mm = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", x)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < k:
+                a = labels[mm.group(1)]
+                loops.append((k - a, sum(1 for q in pk if a <= q <= k), a, k))
+        # (the innermost loop that holds a whole sweep group: three two-pivot steps = 6 packed FMAs per register pair)
+        _, npk, a, b = min(x for x in loops if x[1] >= 60)
+        inside = [x for x in body[a:b + 1] if x.startswith("scratch_")]
+        assert not inside, (m.group(1), "scratch access inside the sweep loop", inside)
+        # the iteration phases: from the end of the sweep loop to the last packed FMA (the gradient increment of P5)
+        loads = [x for x in body[b:pk[-1] + 1] if x.startswith("scratch_load")]
+        assert len(loads) <= 2, (m.group(1), "scratch loads between the sweep and the end of the iteration phases", loads)
+    assert seen == 7
+
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_every_barrier_waits_for_the_waves_lds_operations(isa_text):

@@ -30,6 +30,21 @@ def rel_err(u, u_ref):
     return np.abs(u - r).max(1) / np.maximum(1.0, np.abs(r).max(1))
 
 
+def u0_err(u, u_ref):
+    """SURVEY 8(d), "separately for u0": the same metric over row 0 of the controls alone -- the only row the reference
+    applies (REF:493: `u0 = controls[0, :]` goes to lowLevelControl)."""
+    u = np.asarray(u, float)
+    r = np.asarray(u_ref, float)
+    u0 = u.reshape(r.shape[0], -1, 12)[:, 0]
+    r0 = r.reshape(r.shape[0], -1, 12)[:, 0]
+    return np.abs(u0 - r0).max(1) / np.maximum(1.0, np.abs(r0).max(1))
+
+
+def both_err(u, u_ref):
+    """(all-controls metric, u0 metric) per instance."""
+    return rel_err(u, u_ref), u0_err(u, u_ref)
+
+
 def phases(t, dt, h):
     return np.array([int(v // dt) % h for v in np.asarray(t, float).reshape(-1)], np.int32)
 
