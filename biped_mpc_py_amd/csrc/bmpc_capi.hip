@@ -399,12 +399,16 @@ int bmpc_default_params(bmpc_params* p, int h) {
   p->rho_eq_scale = h < 20 ? 1e3 : 1e3 * 0.03 / 0.045;               // rho_eq = 30 for every horizon
   p->rho_lo = 3e-4; p->rho_hi_f = 1.0; p->rho_hi_m = 100.0; p->kappa = 20.0;
   p->alpha = 1.6; p->eps_pri = 1e-7; p->eps_dua = 1e-7;
-  p->max_iter = h <= 12 ? 400 : 600;       // (worst seen in the soaks: 240 at h = 10, 315 at h = 16 / 20 with the periods below)
+  // (worst seen in the soaks at the reference's weights: 240 at h = 10, 315 at h = 16 / 20 with the periods below.  The caps
+  //  are for the instances that keep re-classifying away from those weights: at R / 100 -- soft end two decades further down
+  //  -- 55 of 16384 standing h = 20 instances needed up to 60 factorisations and 995 iterations; capped at 24 / 600 they were
+  //  reported unsolved by both families.  The mean is untouched: 131.5 iterations either way.)
+  p->max_iter = h <= 12 ? 1000 : 1500;
   p->check_every = 5;
   // (long horizons re-classify every 10 iterations: the 1-in-2000 instances that keep re-classifying need 25-35
   //  factorisations and converge by iteration ~350; capped at 24 they freeze their penalties at iteration 240 and run
   //  into max_iter)
-  p->max_refactor = h > 20 ? 48 : 24;
+  p->max_refactor = 60;
   // Re-classification period ~ (cost of a factorisation) / (cost of an iteration): 10.6 at h = 10, 15.6 at h = 16,
   // 21.5 at h = 20 (profiles/r02_cfg*_phase_cycles.txt).  Measured on MI355X (build_tmp-style A/B, round 2):
   // h = 16: period 20 from iteration 10 is 8 % faster than 10 / 10 (4.3 instead of 5.6 factorisations, 68 instead of

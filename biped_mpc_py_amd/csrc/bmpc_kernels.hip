@@ -78,6 +78,8 @@ __device__ __forceinline__ int sync_workgroup_or(int v) {
 // hides a loop-invariant f32 value from the optimiser at its point of use, so that its f64 conversion is
 // redone there instead of being hoisted into a second, f64, register copy that lives across the loop
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
+// a condition every lane of the wave evaluates alike, as a scalar (the branch on it is a scalar branch)
+#define BMPC_UNIFORM(x) (__builtin_amdgcn_readfirstlane((int)(x)) != 0)
 #endif
 __device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
@@ -806,6 +808,9 @@ solve_body(const DevParams& P, const int B,
   float dsc = 1.f;                            // S[row]
 #define VROW(q) Vr[(q) >> 1][(q) & 1]
 
+  bool piv_bad = false;                       // the last sweep met a pivot below PIV_MIN (uniform: every lane reads the same pivots)
+  float sweep_reg = 0.f;                      // diagonal regularisation of the next sweep (the repeat after a breakdown)
+  constexpr float PIV_REG = 3.0e-5f;
   auto factor = [&]() {
     if constexpr (PROF) t_mark = clock64();
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
@@ -997,9 +1002,25 @@ solve_body(const DevParams& P, const int B,
       float fd = 0.f;
 #pragma unroll
       for (int b = 0; b < 6; ++b) fd = fmaf((float)mkd[b], fv[b], fd);
-      dsc = rsq_approx(gdiag + fd);
+      // (the regularised repeat after a pivot breakdown, see below: K' + reg diag(K'), i.e. S K' S + reg I up to the factor
+      //  1 + reg; reg = 0 otherwise)
+      const float dg = gdiag + fd;
+      if (sweep_reg > 0.f) {                     // (uniform)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) fv[b] = fmaf((float)mkd[b], sweep_reg * dg, fv[b]);
+      }
+      dsc = rsq_approx(dg * (1.f + sweep_reg));
     }
     sm.dsc[slot<H>(row)] = dsc;                 // both lanes of the pair: same value
+    // The sweep below runs in f32 on a matrix whose condition number reaches 1e6 at the reference's weights and 1e7 -- the
+    // reciprocal of the f32 precision -- a decade away from them (Q x 10: 1 .. 2 instances in 16384 met a pivot that had
+    // lost all its digits: NaNs, or a useless inverse and an instance that re-classifies for ever).  Every pivot is
+    // therefore checked (PIV_MIN: a Schur complement of the unit-diagonal matrix below it is rounding noise), and a sweep
+    // that met a bad one is repeated ONCE (the whole factorisation, by the caller: nothing is kept alive across the sweep for
+    // it) on the matrix + PIV_REG I (added to the diagonal before the scaling): its pivots are then >= PIV_REG, and since the inverse only preconditions the residual
+    // form (section 3) the regularisation costs that factorisation some convergence rate in the softest directions, never
+    // the fixed point.  At the reference's weights no instance of the soaks takes the second pass.
+    constexpr float PIV_MIN = 2.0e-6f;
 #pragma unroll
     for (int q = 0; q < HN; ++q) {
       const int jj = q / 6, b = q % 6;
@@ -1031,6 +1052,7 @@ solve_body(const DevParams& P, const int B,
         }
       }
     }
+    float qmax = 0.f, qmin = 1.f;
     // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of half hf
     // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always one static register pair
     // of the half-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the half-0 lanes publish their two entries of the
@@ -1071,6 +1093,11 @@ solve_body(const DevParams& P, const int B,
         BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
         const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
         const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
+        // (pivot check, two instructions: the diagonal of P^-1 holds the reciprocals of the two pivots -- of the second one
+        //  and of the first one's Schur complement against it; both must be positive -- rounding can turn a lost pivot
+        //  negative -- and below 1 / PIV_MIN.  Every lane reads the same values.)
+        qmax = fmaxf(qmax, fmaxf(q00, q11));
+        qmin = fminf(qmin, fminf(q00, q11));
         const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
         float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
         t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
@@ -1125,6 +1152,7 @@ solve_body(const DevParams& P, const int B,
       ws = wsn;
       BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
     }
+    piv_bad = !(qmax < 1.f / PIV_MIN) || !(qmin > 0.f);     // (an infinite reciprocal -- a zero determinant -- fails too)
     if constexpr (PROF) t_sweep += clock64() - t_mark;
   };
 
@@ -1246,6 +1274,8 @@ solve_body(const DevParams& P, const int B,
   for (it = 0; it < P.max_iter;) {
     if (need_factor) {                         // workgroup-uniform
       factor();
+      if (BMPC_UNIFORM(piv_bad) && sweep_reg == 0.f) { sweep_reg = PIV_REG; continue; }   // once more, regularised (not counted)
+      sweep_reg = 0.f;
       ++nfac;
       need_factor = false;
       aa_have = false;                         // another map: the stored state change belongs to the old one

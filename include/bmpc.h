@@ -102,12 +102,14 @@ typedef struct bmpc_params {
                                 fourth root after 16 (rare active-set cycles) */
   double alpha;              /* over-relaxation */
   double eps_pri, eps_dua;   /* relative stopping tolerances */
-  int32_t max_iter;
+  int32_t max_iter;          /* iteration cap (default 1000 at h <= 12, else 1500; worst seen at the reference's weights: 240 / 315) */
   int32_t check_every;       /* stopping test period */
   int32_t adapt_start;       /* first penalty re-classification (default 10; 20 at h = 20) */
   int32_t adapt_every;       /* re-classification period (0 = never; default 10 at h = 10, 20 at h = 16, 20: the
                                 period follows the cost of a factorisation relative to an iteration) */
-  int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached) */
+  int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached); default 60:
+                                a decade or two away from the reference's weights 1 instance in ~300 keeps re-classifying
+                                for up to 60 rounds (damped moves) and then converges; at the reference's weights <= 18 */
   int32_t warm_adapt_start;  /* first re-classification of a warm-started solve (bmpc_set_warm_start); 0 = adapt_start */
   int32_t path;              /* kernel family: BMPC_PATH_AUTO (default: the faster one for h), BMPC_PATH_DENSE (explicit
                                 6h x 6h inverse in registers; h <= 20) or BMPC_PATH_STAGE (stage-structured Riccati solve,

@@ -146,6 +146,7 @@ static inline float wave_sum(float v) {
 #define BMPC_DRAIN_LDS() do { } while (0)
 #define BMPC_FENCE() do { } while (0)
 #define BMPC_OPAQUE(x) do { } while (0)
+#define BMPC_UNIFORM(x) (x)
 #define BMPC_SCHED_BARRIER() do { } while (0)
 
 static float g_bc[1024];

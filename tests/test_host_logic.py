@@ -140,16 +140,17 @@ def test_pack_params_half_defaults_follow_the_horizon():
 def test_solver_defaults_follow_the_horizon():
     """`bmpc_default_params(h)`: the re-classification period follows the cost of a factorisation relative to an
     iteration -- every 10 iterations at h = 10, every 20 at h = 16 and 20 (from iteration 20 and
-    with rho0 = 0.045 at h = 20), 600 instead of 400 iterations allowed; rho_eq = rho x rho_eq_scale stays 30."""
+    with rho0 = 0.045 at h = 20), 1500 instead of 1000 iterations and 60 factorisations allowed (caps for the instances that
+    keep re-classifying away from the reference's weights; round 4); rho_eq = rho x rho_eq_scale stays 30."""
     import biped_mpc_py_amd as bm
-    want = {10: (10, 10, 400, 0.03), 16: (20, 10, 600, 0.03), 20: (20, 20, 600, 0.045)}
+    want = {10: (10, 10, 1000, 0.03), 16: (20, 10, 1500, 0.03), 20: (20, 20, 1500, 0.045)}
     for h, (every, start, max_iter, rho) in want.items():
         mpc = bm.MPC()
         mpc.h = h
         cp = bm.pack_params(mpc, bm.Biped())
         assert (cp.adapt_every, cp.adapt_start, cp.max_iter) == (every, start, max_iter), h
         assert abs(cp.rho - rho) < 1e-12 and abs(cp.rho * cp.rho_eq_scale - 30.0) < 1e-9, h
-        assert cp.check_every == 5 and cp.warm_adapt_start == 5 and cp.kappa == 20.0
+        assert cp.check_every == 5 and cp.warm_adapt_start == 5 and cp.kappa == 20.0 and cp.max_refactor == 60
     cp = bm.pack_params(bm.MPC(), bm.Biped(), solver_options=dict(adapt_every=15, rho=0.02))      # overrides still apply
     assert cp.adapt_every == 15 and cp.rho == 0.02
 

@@ -39,10 +39,9 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
         # are allowed spilled registers -- set-up values stored ONCE and reloaded at the stopping tests (the exact rebuild of
         # the gradient in state space, round 4: ~25 transient registers at the point where the whole loop state is live)
         # and at the outputs; test_no_scratch_access_in_the_hot_loops below holds that none is touched per iteration
-        assert int(meta["vgpr_spill_count"]) <= {8: 0, 10: 0, 12: 0, 14: 0, 16: 8, 18: 24, 20: 24}[h], (h, meta)
-        if h <= 14:
-            assert int(meta["private_segment_fixed_size"]) == 0, (h, meta)       # no scratch
-        assert int(meta["private_segment_fixed_size"]) <= 128, (h, meta)
+        assert int(meta["vgpr_spill_count"]) <= {8: 0, 10: 0, 12: 0, 14: 0, 16: 0, 18: 24, 20: 24}[h], (h, meta)
+        assert int(meta["private_segment_fixed_size"]) <= 128, (h, meta)      # (where nothing spills no scratch instruction exists:
+                                                                               #  test_no_scratch_access_in_the_hot_loops counts them)
         assert int(meta["vgpr_count"]) + meta["agpr_count"] <= 256, (h, meta)      # two waves per SIMD
         lds = int(meta["group_segment_fixed_size"])
         waves = (12 * h + 63) // 64 if h % 5 else 2 * (h // 5) * 64 // 64
@@ -99,6 +98,8 @@ def test_no_scratch_access_in_the_hot_loops(isa_text):
         # the iteration phases: from the end of the sweep loop to the last packed FMA (the gradient increment of P5)
         loads = [x for x in body[b:pk[-1] + 1] if x.startswith("scratch_load")]
         assert len(loads) <= 2, (m.group(1), "scratch loads between the sweep and the end of the iteration phases", loads)
+        if int(m.group(1)) <= 16:               # nothing spills up to h = 16: no scratch instruction at all
+            assert not any(x.startswith("scratch_") for x in body), m.group(1)
     assert seen == 7
 
 
