@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -16,7 +16,7 @@ EXPORTS = (
     "bmpc_effective_penalties",
     "bmpc_default_params",
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
-    "bmpc_solve_batch", "bmpc_solve_batch_device", "bmpc_synchronize",
+    "bmpc_solve_batch", "bmpc_solve_batch_f64", "bmpc_solve_batch_device", "bmpc_synchronize",
     "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
     "bmpc_foot_position_world", "bmpc_foot_position_world_device",
     "bmpc_low_level_control", "bmpc_low_level_control_device",
@@ -106,6 +106,7 @@ def load():
     lib.bmpc_get_params.argtypes = [vp, C.POINTER(CParams)]
     ptrs14 = [vp] * 12
     lib.bmpc_solve_batch.argtypes = [vp, ip] + ptrs14
+    lib.bmpc_solve_batch_f64.argtypes = [vp, ip] + ptrs14
     lib.bmpc_solve_batch_device.argtypes = [vp, ip] + ptrs14 + [vp]
     lib.bmpc_synchronize.argtypes = [vp]
     lib.bmpc_debug_assemble.argtypes = [vp, ip] + [vp] * 10

@@ -113,22 +113,34 @@ class BatchSolver:
             mu = np.ascontiguousarray(np.asarray(mu, np.float32).reshape(B, h, 2))
         return B, x_fb, foot, contact, phase, x_cmd, mu
 
-    def solve(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_states=True):
-        """Host arrays in, host arrays out (fp32 over PCIe, fp64 returned).  Returns
-        (states (B,h,13) | None, controls (B,h,12), info)."""
+    def solve(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_states=True, out=None):
+        """Host arrays in, host arrays out (fp32 over PCIe, fp64 returned -- the reference's dtype, REF:300-304; the
+        widening happens inside `bmpc_solve_batch_f64` while the results are unpacked, overlapped with the solve).  Returns
+        (states (B,h,13) | None, controls (B,h,12), info).  `out`: optional (states | None, controls) fp64 C-contiguous
+        arrays of those shapes to write into (a control loop reuses its buffers instead of allocating 8 MB per call)."""
         B, x_fb, foot, contact, phase, x_cmd, mu = self._marshal(x_fb, foot, contact, phase, x_cmd, mu)
         h = self.h
-        controls = np.empty((B, h, 12), np.float32)
-        states = np.empty((B, h, 13), np.float32) if want_states else None
+        if out is not None:
+            states, controls = out
+            for a, shp in ((states, (B, h, 13)), (controls, (B, h, 12))):
+                if a is not None and not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == shp):
+                    raise ValueError(f"out arrays must be C-contiguous float64 of shape {shp}")
+            if controls is None:
+                raise ValueError("out = (states | None, controls): controls is required")
+            if not want_states:
+                states = None
+        else:
+            controls = np.empty((B, h, 12), np.float64)
+            states = np.empty((B, h, 13), np.float64) if want_states else None
         iters = np.empty(B, np.int32)
         status = np.empty(B, np.int32)
         nfactor = np.empty(B, np.int32)
         resid = np.empty((B, 2), np.float32)
-        _lib.check(self._lib.bmpc_solve_batch(
+        _lib.check(self._lib.bmpc_solve_batch_f64(
             self._h, B, _ptr(x_fb), _ptr(foot), _ptr(contact), _ptr(phase), _ptr(x_cmd), _ptr(mu),
             _ptr(controls), _ptr(states), _ptr(iters), _ptr(resid), _ptr(status), _ptr(nfactor)))
         info = dict(iters=iters, status=status, nfactor=nfactor, residuals=resid)
-        return (None if states is None else states.astype(np.float64)), controls.astype(np.float64), info
+        return states, controls, info
 
     def assemble(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_matrices=True):
         """Assembly stage only (parity tests, reference generators): x_ref (B,h,12), foot_ref (B,h,6) and -- with

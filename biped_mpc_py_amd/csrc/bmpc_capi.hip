@@ -5,7 +5,9 @@
 #include "bmpc_stage.hip"
 #include "bmpc_lowlevel.hip"
 
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -172,6 +174,22 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   return BMPC_OK;
 }
 
+// page-locked host memory (the staging of the host-pointer entry points: copies to and from it run at the full PCIe rate
+// and asynchronously, which pageable memory does not allow)
+struct PinnedBuf {
+  char* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= n) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault);
+    if (e == hipSuccess) n = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -199,7 +217,14 @@ struct bmpc_handle_s {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
-  // staging for the host-pointer entry points
+  // staging for the host-pointer entry points.  bmpc_solve_batch*: ONE packed block of inputs and one of outputs on either side
+  // of PCIe (pinned on the host), the batch solved in up to HOST_CHUNKS chunks on streams of descending priority so that a
+  // chunk's results cross PCIe -- and are unpacked / widened by the calling thread -- while the later chunks still solve
+  static constexpr int HOST_CHUNKS = 3;
+  PinnedBuf pin_in, pin_out;
+  DevBuf<char> dev_in, dev_out;
+  hipStream_t cstream[HOST_CHUNKS] = {nullptr, nullptr, nullptr};
+  hipEvent_t cev[HOST_CHUNKS] = {nullptr, nullptr, nullptr};
   DevBuf<float> x_fb, foot, x_cmd, mu, controls, states, resid;
   DevBuf<uint8_t> contact;
   DevBuf<int32_t> phase, iters, status, nfactor;
@@ -447,6 +472,19 @@ int bmpc_create(bmpc_handle* out, const bmpc_params* params, int device, int max
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  {
+    // chunk streams of the host-pointer path: the first chunk on the highest priority the device offers, the last ones on the
+    // lowest, so that the workgroup dispatcher serves the chunks in order and the first results leave early
+    int least = 0, greatest = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (std::getenv("BMPC_HOST_TIMING")) std::fprintf(stderr, "[bmpc host path] stream priorities: least %d greatest %d\n", least, greatest);
+    for (int c = 0; c < bmpc_handle_s::HOST_CHUNKS && e == hipSuccess; ++c) {
+      int prio = greatest + c;                   // (numerically lower = more urgent)
+      if (prio > least) prio = least;
+      e = hipStreamCreateWithPriority(&h->cstream[c], hipStreamNonBlocking, prio);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&h->cev[c], hipEventDisableTiming);
+    }
+  }
   if (e != hipSuccess) {
     bmpc_destroy(h);
     return fail(BMPC_ERR_HIP, "bmpc_create: %s", hipGetErrorString(e));
@@ -466,6 +504,11 @@ int bmpc_destroy(bmpc_handle h) {
   h->ll_t.release(); h->ll_c0.release();
   h->warm.release(); h->ro_controls.release(); h->ro_states.release(); h->ro_contact.release();
   h->ro_phase.release(); h->ro_iters.release(); h->ro_status.release(); h->ro_order.release();
+  for (int c = 0; c < bmpc_handle_s::HOST_CHUNKS; ++c) {
+    if (h->cstream[c]) { (void)hipStreamSynchronize(h->cstream[c]); (void)hipStreamDestroy(h->cstream[c]); }
+    if (h->cev[c]) (void)hipEventDestroy(h->cev[c]);
+  }
+  h->pin_in.release(); h->pin_out.release(); h->dev_in.release(); h->dev_out.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -520,44 +563,153 @@ int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float
                               stream, h->order);
 }
 
-int bmpc_solve_batch(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
-                     const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
-                     int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor) {
+// Host pointers in, host pointers out (T = float: bmpc_solve_batch; T = double: bmpc_solve_batch_f64, the dtype the reference
+// returns).  What the reference's callers get (REF:487), so PCIe is part of the path:
+//   * per chunk the inputs are packed into one pinned block and cross in ONE copy; outputs come back one packed block;
+//   * the batch is split into up to HOST_CHUNKS contiguous chunks, each launched on its own stream (descending priority:
+//     the dispatcher serves chunk 0's workgroups first), followed on that stream by the chunk's device-to-host copy: the
+//     results of chunk c cross PCIe, and are unpacked (widened to fp64) by the calling thread, while chunks c + 1 .. still
+//     solve.  Only the last chunk's copy and unpacking are exposed.
+// The kernels' arithmetic does not depend on the position in a batch, so the results are bit-identical to a single launch.
+// Warm start, a dispatch order and the profile buffer index by the instance's position in the whole batch: with any of them
+// set the batch goes out as one chunk.
+}  // extern "C"  (a template cannot have C linkage)
+
+namespace {
+
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+template <typename T>
+int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact, const int32_t* phase,
+               const float* x_cmd, const float* mu, T* controls, T* states, int32_t* iters, float* residuals, int32_t* status,
+               int32_t* nfactor) {
   int rc = check_common(h, B, x_fb, foot, contact, phase, controls);
   if (rc != BMPC_OK) return rc;
   if (B == 0) return BMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)B, H = (size_t)h->dev.h;
-  HIP_TRY(h->x_fb.ensure(n * 12)); HIP_TRY(h->foot.ensure(n * 6)); HIP_TRY(h->contact.ensure(n * H * 2));
-  HIP_TRY(h->phase.ensure(n)); HIP_TRY(h->controls.ensure(n * H * 12)); HIP_TRY(h->states.ensure(n * H * 13));
-  HIP_TRY(h->iters.ensure(n)); HIP_TRY(h->status.ensure(n)); HIP_TRY(h->nfactor.ensure(n)); HIP_TRY(h->resid.ensure(n * 2));
-  if (x_cmd) HIP_TRY(h->x_cmd.ensure(n * 12));
-  if (mu) HIP_TRY(h->mu.ensure(n * H * 2));
-  hipStream_t st = h->stream;
-  HIP_TRY(hipMemcpyAsync(h->x_fb.p, x_fb, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(h->foot.p, foot, n * 6 * sizeof(float), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(h->contact.p, contact, n * H * 2, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(h->phase.p, phase, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  if (x_cmd) HIP_TRY(hipMemcpyAsync(h->x_cmd.p, x_cmd, n * 12 * sizeof(float), hipMemcpyHostToDevice, st));
-  if (mu) HIP_TRY(hipMemcpyAsync(h->mu.p, mu, n * H * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-  rc = bmpc_solve_batch_device(h, B, h->x_fb.p, h->foot.p, h->contact.p, h->phase.p, x_cmd ? h->x_cmd.p : nullptr,
-                               mu ? h->mu.p : nullptr, h->controls.p, states ? h->states.p : nullptr, h->iters.p,
-                               h->resid.p, h->status.p, h->nfactor.p, st);
-  if (rc != BMPC_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(controls, h->controls.p, n * H * 12 * sizeof(float), hipMemcpyDeviceToHost, st));
-  if (states) HIP_TRY(hipMemcpyAsync(states, h->states.p, n * H * 13 * sizeof(float), hipMemcpyDeviceToHost, st));
-  if (iters) HIP_TRY(hipMemcpyAsync(iters, h->iters.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  if (status) HIP_TRY(hipMemcpyAsync(status, h->status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  if (nfactor) HIP_TRY(hipMemcpyAsync(nfactor, h->nfactor.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  if (residuals) HIP_TRY(hipMemcpyAsync(residuals, h->resid.p, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  const bool timing = std::getenv("BMPC_HOST_TIMING") != nullptr;     // (diagnostics: where a host-pointer call spends its time)
+  auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = timing ? now() : 0.0;
+  double t_wait = 0, t_unpack = 0, t_last_wait = 0, t_last_unpack = 0;
+  // ---- chunks: contiguous, one per stream priority the device offers (MI355X: three; chunks that share a priority are
+  // served round robin and finish together), the later ones smaller: the last chunk's copy and unpacking are the exposed part,
+  // and a chunk's unpacking (~1/3 of its solve time) has to fit before the next chunk arrives.  Measured (4096 instances,
+  // h = 10): chunks ready 540 / 720 / 890 us after the call, the call returns ~60 us after the last kernel ends.
+  const bool whole = h->warm_on || h->order || h->prof_dev;
+  int nchunk = whole ? 1 : (int)(n / 512);
+  nchunk = nchunk < 1 ? 1 : (nchunk > bmpc_handle_s::HOST_CHUNKS ? bmpc_handle_s::HOST_CHUNKS : nchunk);
+  double kCut4[bmpc_handle_s::HOST_CHUNKS + 1] = {0.0, 0.55, 0.85, 1.0};
+  if (const char* e = std::getenv("BMPC_HOST_CUTS")) {          // (experiments: "0.5,0.8", or "1" for one chunk)
+    double a = 1.0, b = 1.0;
+    const int k = std::sscanf(e, "%lf,%lf", &a, &b);
+    if (k == 1 && a >= 1.0) nchunk = 1;
+    else if (k == 1) { nchunk = nchunk < 2 ? nchunk : 2; kCut4[1] = a; kCut4[2] = 1.0; }
+    else if (k == 2) { kCut4[1] = a; kCut4[2] = b; }
+  }
+  // per-instance bytes of a chunk's packed blocks.  in: x_fb, foot, phase [, x_cmd] [, mu], contact;
+  // out: controls [, states], iters, status, nfactor, residuals (every sub-array starts 16-byte aligned)
+  const size_t in_per = (12 + 6 + 1 + (x_cmd ? 12 : 0) + (mu ? 2 * H : 0)) * 4 + 2 * H;
+  const size_t out_per = (H * 12 + (states ? H * 13 : 0)) * 4 + 3 * 4 + 2 * 4;
+  const size_t in_bytes = n * in_per + (size_t)nchunk * 6 * 16, out_bytes = n * out_per + (size_t)nchunk * 6 * 16;
+  HIP_TRY(h->pin_in.ensure(in_bytes));
+  HIP_TRY(h->dev_in.ensure(in_bytes));
+  HIP_TRY(h->pin_out.ensure(out_bytes));
+  HIP_TRY(h->dev_out.ensure(out_bytes));
+  struct Chunk { size_t lo, nb, off, o_u, o_s, o_it, o_st, o_nf, o_rs, bytes; } ck[bmpc_handle_s::HOST_CHUNKS];
+  size_t off = 0, ioff = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    Chunk& k = ck[c];
+    k.lo = nchunk >= 2 ? (size_t)(n * kCut4[c]) : 0;
+    k.nb = (nchunk >= 2 ? (size_t)(n * kCut4[c + 1]) : n) - k.lo;
+    if (c == nchunk - 1) k.nb = n - k.lo;
+    // inputs of this chunk: packed into the pinned block and sent in ONE copy (chunk 0 is on its way while the later
+    // chunks are still being packed)
+    const size_t i_xfb = 0, i_foot = align16(i_xfb + k.nb * 12 * 4), i_phase = align16(i_foot + k.nb * 6 * 4),
+                 i_xcmd = align16(i_phase + k.nb * 4), i_mu = align16(i_xcmd + (x_cmd ? k.nb * 12 * 4 : 0)),
+                 i_con = align16(i_mu + (mu ? k.nb * H * 2 * 4 : 0)), i_bytes = align16(i_con + k.nb * H * 2);
+    char* pin = h->pin_in.p + ioff;
+    char* din = h->dev_in.p + ioff;
+    ioff += i_bytes;
+    std::memcpy(pin + i_xfb, x_fb + k.lo * 12, k.nb * 12 * 4);
+    std::memcpy(pin + i_foot, foot + k.lo * 6, k.nb * 6 * 4);
+    std::memcpy(pin + i_phase, phase + k.lo, k.nb * 4);
+    if (x_cmd) std::memcpy(pin + i_xcmd, x_cmd + k.lo * 12, k.nb * 12 * 4);
+    if (mu) std::memcpy(pin + i_mu, mu + k.lo * H * 2, k.nb * H * 2 * 4);
+    std::memcpy(pin + i_con, contact + k.lo * H * 2, k.nb * H * 2);
+    k.off = off;
+    k.o_u = 0;
+    k.o_s = align16(k.o_u + k.nb * H * 12 * 4);
+    k.o_it = align16(k.o_s + (states ? k.nb * H * 13 * 4 : 0));
+    k.o_st = align16(k.o_it + k.nb * 4);
+    k.o_nf = align16(k.o_st + k.nb * 4);
+    k.o_rs = align16(k.o_nf + k.nb * 4);
+    k.bytes = align16(k.o_rs + k.nb * 2 * 4);
+    off += k.bytes;
+    hipStream_t st = h->cstream[c];
+    HIP_TRY(hipMemcpyAsync(din, pin, i_bytes, hipMemcpyHostToDevice, st));
+    char* dout = h->dev_out.p + k.off;
+    rc = solve_device_ordered(h, (int)k.nb, reinterpret_cast<const float*>(din + i_xfb), reinterpret_cast<const float*>(din + i_foot),
+                              reinterpret_cast<const uint8_t*>(din + i_con), reinterpret_cast<const int32_t*>(din + i_phase),
+                              x_cmd ? reinterpret_cast<const float*>(din + i_xcmd) : nullptr,
+                              mu ? reinterpret_cast<const float*>(din + i_mu) : nullptr,
+                              reinterpret_cast<float*>(dout + k.o_u), states ? reinterpret_cast<float*>(dout + k.o_s) : nullptr,
+                              reinterpret_cast<int32_t*>(dout + k.o_it), reinterpret_cast<float*>(dout + k.o_rs),
+                              reinterpret_cast<int32_t*>(dout + k.o_st), reinterpret_cast<int32_t*>(dout + k.o_nf), st, h->order);
+    if (rc != BMPC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(h->pin_out.p + k.off, dout, k.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(h->cev[c], st));
+  }
+  const double t_issued = timing ? now() : 0.0;
+  // ---- unpack chunk by chunk, as each arrives
+  for (int c = 0; c < nchunk; ++c) {
+    const Chunk& k = ck[c];
+    const double tw0 = timing ? now() : 0.0;
+    HIP_TRY(hipEventSynchronize(h->cev[c]));
+    const double tw1 = timing ? now() : 0.0;
+    t_wait += tw1 - tw0; t_last_wait = tw1 - tw0;
+    if (timing) std::fprintf(stderr, "[bmpc host path]   chunk %d ready %.0f us after the call began (waited %.0f)\n", c, tw1 - t_begin, tw1 - tw0);
+    const char* src = h->pin_out.p + k.off;
+    auto put = [&](T* dst, const float* from, size_t cnt) {
+      if constexpr (sizeof(T) == sizeof(float)) std::memcpy(dst, from, cnt * sizeof(float));
+      else for (size_t q = 0; q < cnt; ++q) dst[q] = (T)from[q];
+    };
+    put(controls + k.lo * H * 12, reinterpret_cast<const float*>(src + k.o_u), k.nb * H * 12);
+    if (states) put(states + k.lo * H * 13, reinterpret_cast<const float*>(src + k.o_s), k.nb * H * 13);
+    if (iters) std::memcpy(iters + k.lo, src + k.o_it, k.nb * 4);
+    if (status) std::memcpy(status + k.lo, src + k.o_st, k.nb * 4);
+    if (nfactor) std::memcpy(nfactor + k.lo, src + k.o_nf, k.nb * 4);
+    if (residuals) std::memcpy(residuals + k.lo * 2, src + k.o_rs, k.nb * 2 * 4);
+    if (timing) { const double tu = now() - tw1; t_unpack += tu; t_last_unpack = tu; }
+  }
+  if (timing)
+    std::fprintf(stderr, "[bmpc host path] B %d chunks %d: pack + issue %.0f us, waiting %.0f us (last chunk %.0f), unpack %.0f us (last chunk %.0f), total %.0f us\n",
+                 B, nchunk, t_issued - t_begin, t_wait, t_last_wait, t_unpack, t_last_unpack, now() - t_begin);
   return BMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmpc_solve_batch(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                     const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
+                     int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor) {
+  return solve_host<float>(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor);
+}
+
+int bmpc_solve_batch_f64(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
+                         const int32_t* phase, const float* x_cmd, const float* mu, double* controls, double* states,
+                         int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor) {
+  return solve_host<double>(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor);
 }
 
 int bmpc_synchronize(bmpc_handle h) {
   if (!h) return fail(BMPC_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int c = 0; c < bmpc_handle_s::HOST_CHUNKS; ++c)
+    if (h->cstream[c]) HIP_TRY(hipStreamSynchronize(h->cstream[c]));
   if (h->timed) HIP_TRY(hipEventSynchronize(h->ev1));     // the last solve launch, whatever stream it was given
   return BMPC_OK;
 }

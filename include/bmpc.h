@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 8
+#define BMPC_ABI_VERSION 9
 
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
@@ -188,6 +188,24 @@ int bmpc_solve_batch(bmpc_handle h, int B,
                      const int32_t* phase, const float* x_cmd, const float* mu,
                      float* controls, float* states,
                      int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor);
+
+/*
+ * Same with fp64 outputs -- the dtype REF:300-304 returns (`states`, `controls` are fp64 arrays there) -- so that a caller
+ * who needs the reference's dtype does not widen 25 h values per instance in a second pass: the widening happens while the
+ * results are unpacked from the pinned staging block, chunk by chunk, overlapped with the solve of the later chunks.  The
+ * values are the fp32 results of bmpc_solve_batch, exactly (float -> double is exact).
+ *
+ * Both host-pointer entries stage through page-locked memory owned by the handle (one packed block in, one packed block per
+ * chunk out) and split a batch of >= 1024 instances into up to 3 contiguous chunks (55 / 30 / 15 %) on streams of descending priority: a
+ * chunk's device-to-host copy and unpacking overlap the later chunks' solves.  Results do not depend on the chunking (the
+ * kernels' arithmetic does not depend on the position in a batch).  With warm start, a dispatch order or the profile buffer
+ * set the batch goes out as one chunk.
+ */
+int bmpc_solve_batch_f64(bmpc_handle h, int B,
+                         const float* x_fb, const float* foot, const uint8_t* contact,
+                         const int32_t* phase, const float* x_cmd, const float* mu,
+                         double* controls, double* states,
+                         int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor);
 
 /*
  * Same, DEVICE pointers (memory of the handle's device), asynchronous on `stream`

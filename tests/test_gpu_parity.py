@@ -471,6 +471,61 @@ def test_solve_device_is_ordered_on_the_default_stream():
     sol.close()
 
 
+@pytest.mark.parametrize("B,h,kw", [(4099, 10, dict(vx_cmd=True)), (1023, 10, {}), (5, 10, {}), (2051, 20, dict(vx_cmd=True, per_step_mu=True))])
+def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
+    """`bmpc_solve_batch` / `bmpc_solve_batch_f64` (what REF:487 callers get): pinned staging, up to four chunks on streams of
+    descending priority, a chunk's device-to-host copy and fp64 widening overlapped with the later chunks' solves.  The
+    results must not depend on any of that: both entries against ONE launch of `bmpc_solve_batch_device` over the whole batch,
+    bit for bit -- controls, states, iteration counts, status, residuals -- for ragged sizes (chunk boundaries off any power
+    of two, fewer instances than a chunk), optional inputs, `want_states = False`, caller-owned output arrays, and with a
+    dispatch order set (one chunk)."""
+    import ctypes as C
+    import torch
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import _lib
+    s = util.synth_batch(B, h, 900 + B, gait="mixed" if h == 10 else "walking", **kw)
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    dev = torch.device("cuda:0")
+    t = {k: (None if s[k] is None else torch.from_numpy(np.ascontiguousarray(s[k].astype(np.float32) if s[k].dtype == np.float64 else s[k])).to(dev))
+         for k in ("x_fb", "foot", "contact", "phase", "x_cmd", "mu")}
+    o_s = torch.empty((B, h, 13), dtype=torch.float32, device=dev)
+    o_it, o_st, o_nf = (torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3))
+    o_rs = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    u_dev, _ = sol.solve_device(t["x_fb"], t["foot"], t["contact"], t["phase"], t["x_cmd"], t["mu"], states=o_s, iters=o_it,
+                                residuals=o_rs, status=o_st, nfactor=o_nf)
+    torch.cuda.synchronize()
+    u1, s1 = u_dev.cpu().numpy(), o_s.cpu().numpy()
+    # fp64 entry (BatchSolver.solve)
+    st, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])
+    assert u.dtype == np.float64 and st.dtype == np.float64
+    assert np.array_equal(u, u1.astype(np.float64)) and np.array_equal(st, s1.astype(np.float64))
+    assert np.array_equal(info["iters"], o_it.cpu().numpy()) and np.array_equal(info["status"], o_st.cpu().numpy())
+    assert np.array_equal(info["nfactor"], o_nf.cpu().numpy()) and np.array_equal(info["residuals"], o_rs.cpu().numpy())
+    # without states, into caller-owned arrays
+    buf = np.full((B, h, 12), np.nan)
+    st2, u2, _ = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False, out=(None, buf))
+    assert st2 is None and u2 is buf and np.array_equal(buf, u)
+    # fp32 entry through ctypes
+    x32 = [np.ascontiguousarray(s[k].astype(np.float32)) for k in ("x_fb", "foot")]
+    c8, ph = np.ascontiguousarray(s["contact"]), np.ascontiguousarray(s["phase"])
+    xc = None if s["x_cmd"] is None else np.ascontiguousarray(s["x_cmd"].astype(np.float32))
+    mu32 = None if s["mu"] is None else np.ascontiguousarray(s["mu"].astype(np.float32))
+    uf, sf = np.empty((B, h, 12), np.float32), np.empty((B, h, 13), np.float32)
+    itf = np.empty(B, np.int32)
+    P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    _lib.check(sol._lib.bmpc_solve_batch(sol._h, B, P(x32[0]), P(x32[1]), P(c8), P(ph), P(xc), P(mu32), P(uf), P(sf), P(itf), None, None, None))
+    assert np.array_equal(uf, u1) and np.array_equal(sf, s1) and np.array_equal(itf, info["iters"])
+    # a dispatch order indexes the whole batch: one chunk, same results
+    order = torch.arange(B - 1, -1, -1, dtype=torch.int32, device=dev)
+    sol.set_dispatch_order(order)
+    _, u3, i3 = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
+    sol.set_dispatch_order(None)
+    assert np.array_equal(u3, u) and np.array_equal(i3["iters"], info["iters"])
+    sol.close()
+
+
 def test_dropin_reuses_one_handle_and_reports_status():
     """The drop-in wrappers keep ONE handle per (horizon, device) however often the command changes (ADVICE r1:
     one handle per distinct parameter block leaked streams and buffers), answers follow the changed
