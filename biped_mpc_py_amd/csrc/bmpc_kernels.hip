@@ -684,16 +684,20 @@ solve_body(const DevParams& P, const int B,
       RT nw[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) nw[q] = dt * sm.Iw[j][3 * q + a] * (RT)P.Q[6 + q];   // Q_w weighted column
-      RT acc[3 * HH];                           // sum_{i > max(j, j2)} (Me_i,j Q Me_i,j2)[a][b] at b HH + jj
+      // (f32 since round 4: the row of Gt a lane keeps is f32 data anyway, and it no longer enters the fixed point -- the
+      //  gradient is rebuilt in state space -- so the products of the f32 table Me are accumulated in f32: no conversions,
+      //  half the register file of the loop)
+      float acc[3 * HH];                        // sum_{i > max(j, j2)} (Me_i,j Q Me_i,j2)[a][b] at b HH + jj
 #pragma unroll
-      for (int q = 0; q < 3 * HH; ++q) acc[q] = 0;
+      for (int q = 0; q < 3 * HH; ++q) acc[q] = 0.f;
+      const float qe[3] = {(float)P.Q[0], (float)P.Q[1], (float)P.Q[2]};
 #pragma unroll 1
       for (int i = 1; i < H; ++i) {             // uniform
         const bool act = i > j;
         const float* m1 = sm.Me[pair_index(i, act ? j : 0)];
-        RT u[3];
+        float u[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) u[q] = act ? (RT)m1[3 * q + a] * (RT)P.Q[q] : (RT)0;
+        for (int q = 0; q < 3; ++q) u[q] = act ? m1[3 * q + a] * qe[q] : 0.f;
 #pragma unroll
         for (int jj = 0; jj < HH; ++jj) {
           const int j2 = jb + jj;
@@ -702,7 +706,7 @@ solve_body(const DevParams& P, const int B,
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-              for (int b = 0; b < 3; ++b) acc[b * HH + jj] += u[q] * (RT)m2[3 * q + b];
+              for (int b = 0; b < 3; ++b) acc[b * HH + jj] = fmaf(u[q], m2[3 * q + b], acc[b * HH + jj]);
           }
         }
       }
@@ -715,7 +719,7 @@ solve_body(const DevParams& P, const int B,
           RT sw = 0;
 #pragma unroll
           for (int q = 0; q < 3; ++q) sw += nw[q] * dt * sm.Iw[j2][3 * q + b];
-          const RT gval = 2 * (acc[b * HH + jj] + cnt * sw);
+          const RT gval = 2 * ((RT)acc[b * HH + jj] + cnt * sw);
           Grow[b * HH + jj] = (float)gval;
           if (j2 == j && b == a) gdiag = (float)gval;
           if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = gval;     // fp64 view of the row (tests)
