@@ -304,12 +304,43 @@ __device__ __forceinline__ void block_max(float (&v)[NV], float (*red)[NT / 64])
 // the maxima are non-zero in the first 16 lanes of a wave only (step 0's statistics) and take the short reduction
 template <int NT, int NV, int NS, int NR = 0>
 __device__ __forceinline__ void block_max_sum(float (&v)[NV + NS], float (*red)[NT / 64]) {
+#ifndef BMPC_EMU
+  // the DPP steps of all values in lockstep (step by step over the values, not value by value): a DPP operation needs two
+  // wait states after the write of its source, which the other values' steps fill instead of s_nops
+  {
+    unsigned u[NV];
+    float f[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) u[q] = __float_as_uint(v[q]);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) f[q] = v[NV + q];
+#define BMPC_STEP_ALL(ctrl, NMAX)                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < NMAX; ++q) {                                                                         \
+      const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u[q], ctrl, 0xf, 0xf, true); u[q] = u[q] > o ? u[q] : o; } \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q)                                                                             \
+      f[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f[q]), ctrl, 0xf, 0xf, true));
+    BMPC_STEP_ALL(0x111, NV)
+    BMPC_STEP_ALL(0x112, NV)
+    BMPC_STEP_ALL(0x114, NV)
+    BMPC_STEP_ALL(0x118, NV)
+    BMPC_STEP_ALL(0x142, NV - NR)              // (the last NR values live in the first row of 16 lanes only: done)
+    BMPC_STEP_ALL(0x143, NV - NR)
+#undef BMPC_STEP_ALL
+#pragma unroll
+    for (int q = 0; q < NV - NR; ++q) v[q] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u[q], 63));
+#pragma unroll
+    for (int q = NV - NR; q < NV; ++q) v[q] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u[q], 15));
+#pragma unroll
+    for (int q = 0; q < NS; ++q) v[NV + q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f[q]), 63));
+  }
+#else
 #pragma unroll
   for (int q = 0; q < NV - NR; ++q) v[q] = __uint_as_float(wave_umax(__float_as_uint(v[q])));
 #pragma unroll
   for (int q = NV - NR; q < NV; ++q) v[q] = __uint_as_float(row0_umax(__float_as_uint(v[q])));
 #pragma unroll
   for (int q = NV; q < NV + NS; ++q) v[q] = wave_sum(v[q]);
+#endif
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
