@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="instances for the all-core CPU baseline and the in-run parity (0 = skip; default: the whole batch "
                          "at h = 10, i.e. ~4 s on 16 cores, 256 otherwise)")
+    ap.add_argument("--skip-host-path", action="store_true",
+                    help="do not measure the host-pointer (PCIe-inclusive) rate: under rocprofv3 its chunked launches would be "
+                         "averaged into the kernel's statistics (tools/profile_round.sh)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal only: initialise torch.distributed and run the collectives even with one rank")
@@ -630,7 +633,9 @@ def run_rank(args):
                 "mean_iters_rank0": float(R2["iters"].mean()), "not_converged_rank0": int((R2["status"] != 0).sum())}
     if rank == 0 and R["gather_check"]:
         line["config"]["gather_check"] = R["gather_check"]
-    if rank == 0:
+    if rank == 0 and args.skip_host_path:
+        print(json.dumps(line), flush=True)
+    elif rank == 0:
         _log("host-pointer (PCIe-inclusive) rate")
         # whole-batch wall clock through the host-pointer entry (H2D + kernel + D2H, fp32 over PCIe)
         xs = [s[k][lo:hi] for k in ("x_fb", "foot", "contact", "phase")]

@@ -7,12 +7,15 @@ cfgs = sorted(int(os.path.basename(d)[3:]) for d in glob.glob(os.path.join(out, 
 H = {2: 10, 3: 16, 4: 10, 5: 20, 6: 32, 7: 40}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from biped_mpc_py_amd.synth import kernel_source_hash
-def counters(d):
+def counters(d, B=None):
     acc = {}
     fs = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for f in fs[-1:]:                            # the newest run only (gpurun_out accumulates every call's files)
         for r in csv.DictReader(open(f)):
             if "solve_kernel" in r["Kernel_Name"] or "stage_kernel" in r["Kernel_Name"]:
+                # whole-batch launches only (the host-pointer path solves a batch in chunks)
+                if B is not None and int(r["Grid_Size"]) != B * int(r["Workgroup_Size"]):
+                    continue
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 summ = []
@@ -23,7 +26,7 @@ for c in cfgs:
     except Exception:
         continue
     B = line["config"]["batch_per_gpu"]
-    fe, wr = counters(os.path.join(o, "pmc_fetch")), counters(os.path.join(o, "pmc_write"))
+    fe, wr = counters(os.path.join(o, "pmc_fetch"), B), counters(os.path.join(o, "pmc_write"), B)
     s = {"config": c, "batch": B, "horizon": H[c], "source": "profiles/%s_cfg%d_pmc_*.csv" % (tag, c),
          "path": line["config"].get("path", "dense"), "kernel_sha": kernel_source_hash()}
     if "FETCH_SIZE" in fe and "WRITE_SIZE" in wr:
@@ -36,7 +39,7 @@ for c in cfgs:
                      "FETCH_SIZE is NOT doubled: the gfx950 x2 correction is calibrated for 16-B/lane coalesced streams, this kernel reads dwords.")
     sq = {}
     for p in ("pmc_sq1", "pmc_sq2", "pmc_flops"):
-        sq.update({k: v[0] for k, v in counters(os.path.join(o, p)).items()})
+        sq.update({k: v[0] for k, v in counters(os.path.join(o, p), B).items()})
     s["sq_per_launch"] = sq
     if "SQ_INSTS_VALU_FLOPS_FP32" in sq:
         # the counters count flops per LANE of a wave instruction (FMA 2, packed FMA 4, ...), whatever the EXEC mask: x 64

@@ -22,14 +22,14 @@ for c in $cfgs; do
   [ "$c" = 3 ] || [ "$c" = 6 ] || [ "$c" = 7 ] && extra="--batch 4096"
   python3 bench.py --config $c $extra --steps 20 --warmup 3 $([ "$c" = 2 ] || echo "--cpu-sample 0") > "$o/bench.json" 2> "$o/bench.err" || { echo "bench cfg$c failed"; tail -5 "$o/bench.err"; exit 1; }
   echo "cfg$c bench ok: $(cut -c1-160 $o/bench.json)"
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$o/trace" -- python3 "$repo/bench.py" --config $c $extra --steps 20 --warmup 3 --cpu-sample 0 > "$o/bench_under_rocprof.json" 2> "$o/trace.err") || { echo "trace cfg$c failed"; tail -5 "$o/trace.err"; exit 1; }
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$o/trace" -- python3 "$repo/bench.py" --config $c $extra --steps 20 --warmup 3 --cpu-sample 0 --skip-host-path > "$o/bench_under_rocprof.json" 2> "$o/trace.err") || { echo "trace cfg$c failed"; tail -5 "$o/trace.err"; exit 1; }
   echo "cfg$c trace ok"
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
               "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
               "sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_SCA" \
               "flops SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64_TRANS"; do
     set -- $pass; name=$1; shift
-    (cd /tmp && rocprofv3 --pmc $@ --output-format csv -d "$o/pmc_$name" -- python3 "$repo/bench.py" --config $c $extra --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2> "$o/pmc_$name.err") || { echo "pmc $name cfg$c failed"; tail -3 "$o/pmc_$name.err"; }
+    (cd /tmp && rocprofv3 --pmc $@ --output-format csv -d "$o/pmc_$name" -- python3 "$repo/bench.py" --config $c $extra --steps 3 --warmup 1 --cpu-sample 0 --skip-host-path > /dev/null 2> "$o/pmc_$name.err") || { echo "pmc $name cfg$c failed"; tail -3 "$o/pmc_$name.err"; }
     echo "cfg$c pmc $name done"
   done
   if [ "$c" = 2 ]; then
