@@ -157,7 +157,11 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     // The ceilings stay six decades above the soft end (error factor 0.06).
     double rmin = p.R[0];
     for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p.R[i]);
-    const double top = 1e6 * (2 * rmin + rho_lo);
+    // The dense family holds less: its f32 explicit inverse is the preconditioner of every iteration.  At Q x 10 the moment
+    // ceiling resolved to 500 and 2 of 16384 standing h = 20 instances re-classified until the cap, where ceilings of 100 ..
+    // 400 converge every instance in <= 490 iterations at the same mean (tools/soak.py options ... rho_hi_m=10..40): 4e5.  The
+    // stage family (tuned and soaked at 1e6, h = 40: rho_eq = 500) keeps its cap.  Not binding at the reference's weights.
+    const double top = (resolve_path(p.h, p.path) == BMPC_PATH_DENSE ? 4e5 : 1e6) * (2 * rmin + rho_lo);
     rho_eq = std::fmin(rho_eq, top); hi_f = std::fmin(hi_f, top); hi_m = std::fmin(hi_m, top);
     rho0 = std::fmin(rho0, hi_f);
   }

@@ -1634,7 +1634,11 @@ solve_body(const DevParams& P, const int B,
         constexpr float NEAR = 1.0e4f;
         const bool nearby = !(v5[0] > NEAR * tol_p || v5[1] > NEAR * tol_s);
         const int age = it - last_exact;
-        const bool rebuild = nearby && age >= REFRESH_ITERS;
+        // (and every FAR_REFRESH iterations wherever the instance is: one that re-classifies for hundreds of iterations --
+        //  1 in 10^4 a decade away from the reference's weights -- otherwise never comes near, drifts, and then cycles for good:
+        //  1 of 16384 standing instances at Q x 10 ran into the iteration cap that way, 505 iterations with this)
+        constexpr int FAR_REFRESH = 100;
+        const bool rebuild = (nearby && age >= REFRESH_ITERS) || age >= FAR_REFRESH;
         const bool done = small && slow_ok && age <= REFRESH_ITERS + 2 * check_every;
         force_adapt = small && !slow_ok && !bad && it < P.max_iter;
         next_check += far ? 2 * check_every : check_every;

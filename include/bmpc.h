@@ -120,7 +120,8 @@ typedef struct bmpc_params {
                                 there), at h = 10 for h > 20 (the stiff end then grows like sum k^2 ~ h^3) -- and are
                                 scaled by the curvature of the problem at hand relative to it: stiff end (Q, dt, m, I, h)
                                 for the ceilings and rho_eq, 2 R for the floor, their geometric mean for the start.  The
-                                ceilings and rho_eq are capped at 1e6 (2 min R + rho_lo), what the f32 factors hold.
+                                ceilings and rho_eq are capped at 1e6 (2 min R + rho_lo) -- 4e5 on the dense family --, what
+                                the f32 factors hold.
                                 Degenerate curvature scales (every Q of a state group zero) are BMPC_ERR_INVALID, not a
                                 silent fallback.  BMPC_PENALTY_ABSOLUTE: the fields are taken as they are.
                                 bmpc_effective_penalties() returns what a block resolves to. */

@@ -61,7 +61,15 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
         assert lds <= 2000 * steps + 6000 * n_w, (n_p, n_w, lds)    # ~2 KB per step + the block-algebra scratch of one pass
         assert 160 * 1024 // lds >= 2, (n_p, n_w, lds)              # at least two instances per CU at h = 40
         assert int(meta["vgpr_spill_count"]) == 0 and int(meta["private_segment_fixed_size"]) == 0, (n_p, n_w, meta)
-        assert int(meta["vgpr_count"]) <= 512, (n_p, n_w, meta)          # (unified register file: the count includes the AGPRs)
+        # What the family costs in registers, stated as it is (the round-3 test asserted `vgpr_count <= 512`, the
+        # hardware maximum): every variant needs MORE than 256 of the unified 512 registers (the count includes the AGPRs it
+        # parks values in), i.e. one wave per SIMD, and keeps ~200 uniform values in lanes of VGPRs (SGPR spills: v_writelane /
+        # v_readlane, no scratch).  These bounds are regression guards for DESIGN.md section 5b's numbers, not targets.
+        assert 256 < int(meta["vgpr_count"]) <= 512, (n_p, n_w, meta)
+        assert int(meta["sgpr_spill_count"]) <= 230, (n_p, n_w, meta)
+        # instances per CU: LDS admits 160 KB / lds, one wave per SIMD admits 4 / n_w -- the smaller one is what DESIGN.md quotes
+        per_cu = min(160 * 1024 // lds, 4 // n_w)
+        assert per_cu == {(2, 1): 4, (3, 1): 4, (4, 1): 3, (5, 1): 3, (3, 2): 2, (4, 2): 2}[(n_p, n_w)], (n_p, n_w, per_cu)
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_no_scratch_access_in_the_hot_loops(isa_text):
