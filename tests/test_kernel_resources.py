@@ -69,7 +69,7 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
         assert int(meta["sgpr_spill_count"]) <= 230, (n_p, n_w, meta)
         # instances per CU: LDS admits 160 KB / lds, one wave per SIMD admits 4 / n_w -- the smaller one is what DESIGN.md quotes
         per_cu = min(160 * 1024 // lds, 4 // n_w)
-        assert per_cu == {(2, 1): 4, (3, 1): 4, (4, 1): 3, (5, 1): 3, (3, 2): 2, (4, 2): 2}[(n_p, n_w)], (n_p, n_w, per_cu)
+        assert per_cu == {(2, 1): 4, (3, 1): 4, (4, 1): 4, (5, 1): 3, (3, 2): 2, (4, 2): 2}[(n_p, n_w)], (n_p, n_w, per_cu)
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_no_scratch_access_in_the_hot_loops(isa_text):
