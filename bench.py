@@ -524,7 +524,7 @@ def run_rank(args):
     # N > 1, default (weak) mode: the north_star partition measured in the same run -- ONE 65536 batch of config 4 (mixed gait
     # schedules) sharded over the ranks, broadcast + solve + all_gather per step, gather checked bit for bit
     R2 = None
-    if world > 1 and not strong and not args.no_gather and not args.no_strong_record:
+    if use_dist and not strong and not args.no_gather and not args.no_strong_record:      # (N > 1; one rank under --force-dist)
         R2 = timed_run(4, True, "auto", args.steps, args.warmup, total_arg=args.total)
         R2["solver"].close()
 

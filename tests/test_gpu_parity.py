@@ -629,6 +629,30 @@ def test_bench_bare_n_gpus_reports_the_north_star_partition_and_proves_its_rank_
     assert abs(rf["frac"] - rf["frac_survey_formula"]) < 1e-12 and rf["frac_executed"] < rf["frac"]
 
 
+def test_bench_collectives_over_rccl_single_rank_rehearsal():
+    """The N > 1 code path of bench.py over RCCL itself, as far as one GPU allows: `--force-dist` initialises the nccl process
+    group with ONE rank and runs every collective of the line for real -- the parameter broadcast, the asynchronous
+    all_gather_into_tensor of the controls inside the timed step, all_gather_object of the device identities, the all_reduce
+    of the timings, and the `strong` record's broadcast + all_gather + bit-exact gather check.  (Two ranks need two GPUs over
+    RCCL; the two-rank tests above run over gloo.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--total", "8193", "--cpu-sample", "0", "--skip-host-path"], env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([x for x in p.stdout.decode().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collectives_in_step"] == ["all_gather(controls)"]
+    rk = line["ranks"]
+    assert rk["world_size_backend"] == 1 and rk["backend"] == "nccl" and rk["distinct_devices"] == 1 and "uuid" in rk["devices"][0]
+    sr = line["strong"]
+    assert sr["total"] == 8193 and "bit-identical" in sr["gather_check"] and sr["not_converged_rank0"] == 0
+
+
 @pytest.mark.parametrize("gait", ["standing", "walking"])
 def test_closed_loop_rollout_and_warm_start(gait):
     """K = 20 control periods on the device (`bmpc_rollout_device`: schedule -> solve -> state
