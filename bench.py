@@ -153,6 +153,14 @@ def flops_run(h, iters, nfactor):
     return f_setup + nfactor * f_factor + iters * f_iter, dict(setup=f_setup, factor=f_factor, iteration=f_iter)
 
 
+def mfma_count(h):
+    """v_mfma_f64_16x16x4_f64 instructions per solve of the dense family (bmpc_kernels.hip, phase B: the torque block of the
+    wrench-space Hessian Gt = M' M, four rows of M per instruction): ceil(3 (h - 1) / 4) + ceil(3 h / 4) per 16 x 16 tile, for the
+    NTL (NTL + 1) / 2 tiles of the upper triangle, NTL = ceil(3 h / 16).  Each is 16 x 16 x 4 MACs = 2048 flops (f64)."""
+    ntl = -(-3 * h // 16)
+    return (ntl * (ntl + 1) // 2) * (-(-3 * (h - 1) // 4) + -(-3 * h // 4))
+
+
 def stage_variant(h):
     """(steps a lane owns, waves per instance) of the stage-structured kernel that serves horizon h
     (bmpc_stage.hip: stage_steps_per_lane / stage_waves): one wave up to h = 24, two from h = 26."""
@@ -549,7 +557,8 @@ def run_rank(args):
                                               f"({pm.get('kernel_sha')} != {ksha}): refused; rerun tools/profile_round.sh")
                             continue
                         traffic = pm["traffic_bytes_per_launch"]
-                        mfma_ops = pm.get("sq_per_launch", {}).get("SQ_INSTS_VALU_MFMA_MOPS_F32")
+                        sqc = pm.get("sq_per_launch", {})
+                        mfma_ops = {k: sqc[k] for k in ("SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA") if k in sqc} or None
                         hw_flops = pm.get("valu_flops_per_launch")
                         traffic_source = "replayed from " + pm.get("source", "profiles/pmc_summary.json") + \
                                          " (rocprofv3 --pmc passes of this command; not measured in this run)"
@@ -582,7 +591,12 @@ def run_rank(args):
                          "frac": ach_s / PEAK_FP32_TFLOPS,
                          "achieved_survey_formula": ach_s, "frac_survey_formula": ach_s / PEAK_FP32_TFLOPS,
                          "achieved_executed": ach, "frac_executed": ach / PEAK_FP32_TFLOPS,
-                         "mfma_util": 0.0, "mfma_ops_counter": mfma_ops,
+                         # the matrix cores: the Hessian-block GEMM of the set-up (dense family); share of the f64 matrix peak
+                         # = the instruction count of the code x 2048 flops / launch duration (the PMC counter, replayed, agrees)
+                         "mfma_util": (mfma_count(h) * 2048.0 * B / (kernel_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if path_used == "dense" else 0.0,
+                         "mfma_peak": {"value": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "what": "f64 matrix (= f64 vector) peak: the GEMM runs on v_mfma_f64_16x16x4_f64"},
+                         "mfma_instructions_per_solve": mfma_count(h) if path_used == "dense" else 0,
+                         "mfma_ops_counter": mfma_ops,
                          "valu_flops_counter": (None if not hw_flops else {
                              "f32_per_launch": hw_flops["f32"], "f64_per_launch": hw_flops["f64"],
                              "tflops": (hw_flops["f32"] + hw_flops["f64"]) / (kernel_ms * 1e-3) / 1e12,
@@ -599,9 +613,12 @@ def run_rank(args):
                                  "F(h, k) = F_setup + k F_iter per solve x the solves of a launch over the average launch duration, "
                                  "against the f32 vector peak (= the f32 matrix peak on CDNA4); `*_executed`: the flops of the "
                                  "algorithm that runs, symmetric work counted once (round 3 reported this one as `frac`).  "
-                                 "mfma_util is 0 by construction: no MFMA instruction in "
-                                 "either kernel family (SQ_INSTS_VALU_MFMA_MOPS_F32 = 0 in profiles/); the wrench-space form "
-                                 "removes the Hessian GEMM, two matrix-core sweeps were built and measured slower (DESIGN 9). "
+                                 "mfma_util: the one dense horizon-block GEMM of the path -- the torque block of the wrench-space "
+                                 "Hessian, Gt_tt = M' M -- runs on the matrix cores (v_mfma_f64_16x16x4_f64: 45 instructions per solve "
+                                 "at h = 10, 300 at h = 20; f64 because the row it fills is also the operator of the carried gradient's "
+                                 "increments: accumulated in f32 the at-scale error maxima rose tenfold); the wrench-space form leaves no other GEMM "
+                                 "(the 12h x 12h Hessian is never formed), and two matrix-core sweeps of the factorisation were built "
+                                 "and measured slower (DESIGN 9): the f32 matrix rate equals the f32 vector rate on CDNA4. "
                                  "The path is latency-bound: chains of dependent LDS exchanges, not a pipe",
                          "hbm_algorithmic_bytes_per_solve": hbm_bytes_per_solve(h, use_x_cmd, s["mu"] is not None)},
         }

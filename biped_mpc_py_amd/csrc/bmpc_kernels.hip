@@ -89,6 +89,15 @@ __device__ __forceinline__ double pair_swap(double v) {
 }
 __device__ __forceinline__ f2 pair_swap(f2 v) { return f2{pair_swap(v.x), pair_swap(v.y)}; }
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#ifndef BMPC_EMU
+// D += A B on the matrix cores in f64 (v_mfma_f64_16x16x4_f64): lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; it holds D[row = (l >> 4) + 4 reg][col = l & 15] in reg = 0 .. 3.  All 64 lanes of the wave call.
+__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+#endif
+
 struct DevParams {
   int h, half, max_iter, check_every, adapt_start, adapt_every, max_refactor;
   float r2min;                                 // 2 min R: the softest curvature of the problem
@@ -192,12 +201,24 @@ struct IterScratch {
   // set-up only
   RT Rv[H][9];               // R_inv (REF:160-164)
 };
+// Set-up: the torque block of Gt leaves the matrix cores as 16 x 16 accumulator tiles -- the NU = NTL (NTL + 1) / 2 tiles (I <= J)
+// of the symmetric tiling of its 3 H rows -- and is handed to the lanes that keep its rows through LDS, as the f32 values the rows
+// are kept in (17 floats per row: the transposed reads of the blocks below the diagonal hit distinct banks)
+template <int H>
+struct GramTiles {
+  static constexpr int N3 = 3 * H;                       // torque rows
+  static constexpr int NTL = (N3 + 15) / 16;
+  static constexpr int NU = NTL * (NTL + 1) / 2;
+  __host__ __device__ static constexpr int index(int I, int J) { return I * NTL - I * (I - 1) / 2 + (J - I); }   // I <= J
+  float t[NU][16][17];
+};
 template <int H>
 struct alignas(16) Smem {
   static constexpr int NW = Dims<H>::NW;
   union alignas(16) {
     FacScratch<H> fac;
     IterScratch<H> itv;
+    GramTiles<H> gram;
   } u;
   // the two pivot columns of a sweep step, double buffered, two-half layout; behind each one dump slot per row:
   // the half-1 lanes, which hold no pivot-column entry, store there instead of branching around the store
@@ -709,51 +730,75 @@ solve_body(const DevParams& P, const int B,
   float gdiag = 0.f;                           // Gt[row][row] (for the Jacobi scaling of Gt + F); both lanes of the pair
 #pragma unroll
   for (int q = 0; q < GH; ++q) Grow[q] = 0.f;
+  // The torque block is a Gram matrix -- the dense horizon-block GEMM inside the condensed Hessian -- and is formed on the MATRIX
+  // CORES (round 4): Gt_tt = M' M with M the (6 H - 3) x 3 H matrix whose rows are, per state step i and axis q,
+  //   sqrt(2 Q_e[q]) Me[i][j][q][a]   (j < i;  the Euler angles of step i against the torque of step j: REF:165-171, 174-179)
+  //   sqrt(2 Q_w[q]) dt Iw_j[q][a]    (j <= i; the angular velocity of step i)
+  // in the columns (j, a).  v_mfma_f64_16x16x4_f64 takes four rows of M per instruction: a lane supplies ONE entry of them for
+  // A = M' and one for B = M (the same entry on a diagonal tile); the 16 x 16 tiles (I <= J) of the symmetric tiling go round
+  // the waves.  In f64: the row a lane keeps is f32, but it is also the operator of the carried gradient's increments, and
+  // what a batch's worst instances end at follows its accuracy -- accumulated in f32 (vector loop or v_mfma_f32_32x32x2_f32 alike)
+  // the at-scale maxima of config 5 rose from 2.5e-6 to 2.5e-5 (all controls) and from 6.5e-6 to 4.9e-5 (u0).
+  {
+    constexpr int N3 = GramTiles<H>::N3, NTL = GramTiles<H>::NTL, NU = GramTiles<H>::NU, NWV = Dims<H>::NWV;
+    const int wv = l >> 6, ln = l & 63;
+    const int kq = ln >> 4;                    // which of the four rows of M of a step this lane supplies
+    const double sqe[3] = {sqrt(2.0 * P.Q[0]), sqrt(2.0 * P.Q[1]), sqrt(2.0 * P.Q[2])};
+    const double sqw[3] = {P.dt * sqrt(2.0 * P.Q[6]), P.dt * sqrt(2.0 * P.Q[7]), P.dt * sqrt(2.0 * P.Q[8])};
+    const float* MeF = &sm.Me[0][0];
+    auto entry_e = [&](const int k, const int col) -> double {           // Euler rows: k = 3 (i - 1) + q
+      const int i = 1 + k / 3, q = k - 3 * (k / 3), jc = col / 3, ac = col - 3 * jc;
+      const bool ok = k < 3 * (H - 1) && col < N3 && jc < i;
+      const double v = (double)MeF[ok ? pair_index(i, jc) * 9 + 3 * q + ac : 0];
+      return ok ? v * (q == 0 ? sqe[0] : (q == 1 ? sqe[1] : sqe[2])) : 0.0;
+    };
+    auto entry_w = [&](const int k, const int col) -> double {           // angular-velocity rows: k = 3 i + q
+      const int i = k / 3, q = k - 3 * i, jc = col / 3, ac = col - 3 * jc;
+      const bool ok = k < 3 * H && col < N3 && jc <= i;
+      const double v = sm.Iw[ok ? jc : 0][3 * q + ac];
+      return ok ? v * (q == 0 ? sqw[0] : (q == 1 ? sqw[1] : sqw[2])) : 0.0;
+    };
+#pragma unroll 1
+    for (int t = wv; t < NU; t += NWV) {       // (wave-uniform)
+      int ti = 0, tj = t;                      // tile (ti <= tj) number t of the row-major list of the upper triangle
+      while (tj >= NTL - ti) { tj -= NTL - ti; ++ti; }
+      tj += ti;
+      const int colA = 16 * ti + (ln & 15), colB = 16 * tj + (ln & 15);
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+      for (int k0 = 0; k0 < 3 * (H - 1); k0 += 4) {
+        const double av = entry_e(k0 + kq, colA);
+        const double bv = (ti == tj) ? av : entry_e(k0 + kq, colB);
+        acc = mfma_f64_16x16x4(av, bv, acc);
+      }
+#pragma unroll 1
+      for (int k0 = 0; k0 < 3 * H; k0 += 4) {
+        const double av = entry_w(k0 + kq, colA);
+        const double bv = (ti == tj) ? av : entry_w(k0 + kq, colB);
+        acc = mfma_f64_16x16x4(av, bv, acc);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sm.u.gram.t[t][kq + 4 * v][ln & 15] = (float)acc[v];
+    }
+  }
+  sync_workgroup();
   if (valid) {
     if (c < 3) {
       const int a = c;
-      RT nw[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) nw[q] = dt * sm.Iw[j][3 * q + a] * (RT)P.Q[6 + q];   // Q_w weighted column
-      // (f32 since round 4: the row of Gt a lane keeps is f32 data anyway, and it no longer enters the fixed point -- the
-      //  gradient is rebuilt in state space -- so the products of the f32 table Me are accumulated in f32: no conversions,
-      //  half the register file of the loop)
-      float acc[3 * HH];                        // sum_{i > max(j, j2)} (Me_i,j Q Me_i,j2)[a][b] at b HH + jj
-#pragma unroll
-      for (int q = 0; q < 3 * HH; ++q) acc[q] = 0.f;
-      const float qe[3] = {(float)P.Q[0], (float)P.Q[1], (float)P.Q[2]};
-#pragma unroll 1
-      for (int i = 1; i < H; ++i) {             // uniform
-        const bool act = i > j;
-        const float* m1 = sm.Me[pair_index(i, act ? j : 0)];
-        float u[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) u[q] = act ? m1[3 * q + a] * qe[q] : 0.f;
-#pragma unroll
-        for (int jj = 0; jj < HH; ++jj) {
-          const int j2 = jb + jj;
-          if (j2 < i) {
-            const float* m2 = sm.Me[pair_index(i, j2)];
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-              for (int b = 0; b < 3; ++b) acc[b * HH + jj] = fmaf(u[q], m2[3 * q + b], acc[b * HH + jj]);
-          }
-        }
-      }
+      const int r = 3 * j + a;                  // this lane's torque row
 #pragma unroll
       for (int jj = 0; jj < HH; ++jj) {
         const int j2 = jb + jj;
-        const RT cnt = (RT)(H - (j > j2 ? j : j2));
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          RT sw = 0;
-#pragma unroll
-          for (int q = 0; q < 3; ++q) sw += nw[q] * dt * sm.Iw[j2][3 * q + b];
-          const RT gval = 2 * ((RT)acc[b * HH + jj] + cnt * sw);
-          Grow[b * HH + jj] = (float)gval;
-          if (j2 == j && b == a) gdiag = (float)gval;
-          if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = gval;     // fp64 view of the row (tests)
+          const int cb = 3 * j2 + b;
+          // tile (I <= J) holds the block as it is, the block (J, I) below the diagonal is its transpose
+          const int rI = r >> 4, cJ = cb >> 4, rr = r & 15, cc = cb & 15;
+          const bool tr = rI > cJ;
+          const float gv = sm.u.gram.t[GramTiles<H>::index(tr ? cJ : rI, tr ? rI : cJ)][tr ? cc : rr][tr ? rr : cc];
+          Grow[b * HH + jj] = gv;
+          if (j2 == j && b == a) gdiag = gv;
+          if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = (double)gv;     // view of the row (tests)
         }
       }
     } else {
@@ -775,6 +820,7 @@ solve_body(const DevParams& P, const int B,
     }
   }
   gdiag += pair_swap(gdiag);                   // one lane of the pair holds it, the other 0
+  sync_workgroup();                            // (the accumulator tiles share their LDS with the exchange vectors of the gradient)
   // qt = 2 Gam_t' Q (s - x_ref): the exact gradient at u = 0
   const RT qt = gradient_exact(false);
   if (dbg.qt && hf == 0 && real) dbg.qt[(size_t)inst * NW + row] = (double)qt;

@@ -72,6 +72,27 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
         assert per_cu == {(2, 1): 4, (3, 1): 4, (4, 1): 4, (5, 1): 3, (3, 2): 2, (4, 2): 2}[(n_p, n_w)], (n_p, n_w, per_cu)
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
+def test_hessian_block_gemm_runs_on_the_matrix_cores(isa_text):
+    """north_star: "MFMA used only for the dense horizon-block GEMMs inside the condensed Hessian".  The one such GEMM of the
+    wrench-space form -- the torque block Gt_tt = M' M of the set-up -- is formed with v_mfma_f64_16x16x4_f64 in every dense
+    kernel (two accumulation loops: Euler rows, angular-velocity rows; f64: the row it fills is also the operator of the carried
+    gradient's increments), and nowhere else: the stage family never forms Gt."""
+    lines = isa_text.splitlines()
+    seen = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r"_ZN4bmpc\d+(solve|stage)_kernel(?:_prof)?ILi(\d+)E(?:Li\d+E)?E\S*:", ln)
+        if not m:
+            continue
+        end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        n = sum(1 for x in lines[i + 1:end] if x.split(";")[0].strip().startswith("v_mfma_f64_16x16x4"))
+        any_mfma = sum(1 for x in lines[i + 1:end] if x.split(";")[0].strip().startswith("v_mfma"))
+        assert any_mfma == n, ln
+        seen.setdefault(m.group(1), []).append(n)
+    assert len(seen["solve"]) == 14 and all(n >= 2 for n in seen["solve"]), seen
+    assert all(n == 0 for n in seen["stage"]), seen
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_no_scratch_access_in_the_hot_loops(isa_text):
     """Where a dense kernel spills (h >= 16), the spilled values are stored during the set-up and reloaded in code that
     runs at stopping tests / on the way out only: no scratch instruction sits in the body of the sweep loop or of the ADMM

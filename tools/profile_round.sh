@@ -26,7 +26,7 @@ for c in $cfgs; do
   echo "cfg$c trace ok"
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
               "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-              "sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_SCA" \
+              "sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_SCA" \
               "flops SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64_TRANS"; do
     set -- $pass; name=$1; shift
     (cd /tmp && rocprofv3 --pmc $@ --output-format csv -d "$o/pmc_$name" -- python3 "$repo/bench.py" --config $c $extra --steps 3 --warmup 1 --cpu-sample 0 --skip-host-path > /dev/null 2> "$o/pmc_$name.err") || { echo "pmc $name cfg$c failed"; tail -3 "$o/pmc_$name.err"; }
