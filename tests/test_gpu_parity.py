@@ -653,6 +653,36 @@ def test_bench_collectives_over_rccl_single_rank_rehearsal():
     assert sr["total"] == 8193 and "bit-identical" in sr["gather_check"] and sr["not_converged_rank0"] == 0
 
 
+def test_bench_default_line_carries_the_contract_and_the_secondary_records():
+    """The driver's N = 1 run (`python bench.py`, shortened here): the contract's keys, `roofline` and `cpu_baseline`, the parity
+    of the timed batch, and the two secondary rates -- the host-pointer path and two batches in flight -- each bit-identical to
+    the timed device-resident solve."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-sample", "64"],
+                       env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = [x for x in p.stdout.decode().splitlines() if x.strip()]
+    assert len(out) == 1                                  # ONE JSON line on stdout
+    line = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["config"]["baseline_config"] == 2 and line["config"]["not_converged"] == 0
+    rf = line["roofline"]
+    assert rf["frac"] == rf["frac_survey_formula"] and 0 < rf["frac"] < 1 and rf["kernel_ms"] <= line["ms_per_step"] * 1.02
+    assert rf["mfma_instructions_per_solve"] == 45 and rf["mfma_util"] > 0
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["parity"]["max_rel_err_vs_oracle"] <= 1e-5 and line["parity"]["u0_max_rel_err"] <= 2e-5
+    assert line["value_incl_pcie"]["bit_identical_to_device_path"] and line["value_incl_pcie"]["value"] > 0
+    two = line["two_batches_in_flight"]
+    assert two["bit_identical_to_one_at_a_time"] and two["streams"] == 2 and two["value"] > 0.9 * line["value"]
+
+
 @pytest.mark.parametrize("gait", ["standing", "walking"])
 def test_closed_loop_rollout_and_warm_start(gait):
     """K = 20 control periods on the device (`bmpc_rollout_device`: schedule -> solve -> state
