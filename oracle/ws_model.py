@@ -396,6 +396,9 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
             cnt_len = 0
             changed = (rnew != rv).reshape(B, -1).any(1) & active & (n_factor <= P.max_refactor)
             if changed.any():
+                if getattr(P, "trace", None) is not None:           # (tools: how many steps a re-factorisation really touches)
+                    nst = (rnew != rv).any(axis=(2, 3)).sum(1)
+                    P.trace.append((it + 1, n_factor[changed].copy(), nst[changed].copy()))
                 rv = np.where(changed[:, None, None, None], rnew, rv)
                 L, Na, V = fac(rv)                                   # model: refactor all
                 n_factor += changed
