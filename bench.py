@@ -155,10 +155,11 @@ def flops_run(h, iters, nfactor):
 
 def mfma_count(h):
     """v_mfma_f64_16x16x4_f64 instructions per solve of the dense family (bmpc_kernels.hip, phase B: the torque block of the
-    wrench-space Hessian Gt = M' M, four rows of M per instruction): ceil(3 (h - 1) / 4) + ceil(3 h / 4) per 16 x 16 tile, for the
+    wrench-space Hessian Gt = M' M, four rows of M per instruction): ceil(3 (h - 1) / 4) for the Euler rows + 1 for the angular-
+    velocity rows (the same three rows at every state step: a rank-3 product and a count) per 16 x 16 tile, for the
     NTL (NTL + 1) / 2 tiles of the upper triangle, NTL = ceil(3 h / 16).  Each is 16 x 16 x 4 MACs = 2048 flops (f64)."""
     ntl = -(-3 * h // 16)
-    return (ntl * (ntl + 1) // 2) * (-(-3 * (h - 1) // 4) + -(-3 * h // 4))
+    return (ntl * (ntl + 1) // 2) * (-(-3 * (h - 1) // 4) + 1)
 
 
 def stage_variant(h):
@@ -645,8 +646,8 @@ def run_rank(args):
                                  "against the f32 vector peak (= the f32 matrix peak on CDNA4); `*_executed`: the flops of the "
                                  "algorithm that runs, symmetric work counted once (round 3 reported this one as `frac`).  "
                                  "mfma_util: the one dense horizon-block GEMM of the path -- the torque block of the wrench-space "
-                                 "Hessian, Gt_tt = M' M -- runs on the matrix cores (v_mfma_f64_16x16x4_f64: 45 instructions per solve "
-                                 "at h = 10, 300 at h = 20; f64 because the row it fills is also the operator of the carried gradient's "
+                                 "Hessian, Gt_tt = M' M -- runs on the matrix cores (v_mfma_f64_16x16x4_f64: 24 instructions per solve "
+                                 "at h = 10, 160 at h = 20; f64 because the row it fills is also the operator of the carried gradient's "
                                  "increments: accumulated in f32 the at-scale error maxima rose tenfold); the wrench-space form leaves no other GEMM "
                                  "(the 12h x 12h Hessian is never formed), and two matrix-core sweeps of the factorisation were built "
                                  "and measured slower (DESIGN 9): the f32 matrix rate equals the f32 vector rate on CDNA4. "

@@ -124,6 +124,7 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     d->R2[i] = 2.0 * p.R[i];
     if (!(p.R[i] > 0) || !(p.Q[i] >= 0)) return fail(BMPC_ERR_INVALID, "need R > 0, Q >= 0");
   }
+  for (int k = 0; k < 3; ++k) { d->sq_e[k] = std::sqrt(2.0 * p.Q[k]); d->sq_w[k] = p.dt * std::sqrt(2.0 * p.Q[6 + k]); }
   if (!inv3(p.I, d->Iinv)) return fail(BMPC_ERR_INVALID, "inertia matrix is singular");
   for (int i = 0; i < 3; ++i) {
     d->f_max[i] = p.f_max[i]; d->f_min[i] = p.f_min[i];

@@ -103,6 +103,7 @@ struct DevParams {
   float r2min;                                 // 2 min R: the softest curvature of the problem
   double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
   double x_cmd[12], Q[12], R2[12], Iinv[9];    // R2 = 2 R;  Iinv = inverse body inertia
+  double sq_e[3], sq_w[3];                     // sqrt(2 Q_euler), dt sqrt(2 Q_omega): the row scales of the Hessian-block GEMM (set-up)
   double f_max[3], f_min[3], tau_max[3], tau_min[3];
   float rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m, eps_pri, eps_dua, kappa;
   int accel;                                   // secant extrapolation of the iterate at the stopping tests (dense family)
@@ -202,15 +203,17 @@ struct IterScratch {
   RT Rv[H][9];               // R_inv (REF:160-164)
 };
 // Set-up: the torque block of Gt leaves the matrix cores as 16 x 16 accumulator tiles -- the NU = NTL (NTL + 1) / 2 tiles (I <= J)
-// of the symmetric tiling of its 3 H rows -- and is handed to the lanes that keep its rows through LDS, as the f32 values the rows
-// are kept in (17 floats per row: the transposed reads of the blocks below the diagonal hit distinct banks)
+// of the symmetric tiling of its 3 H rows -- and is handed to the lanes that keep its rows through LDS as a dense row-major
+// matrix of the f32 values the rows are kept in: a tile is stored twice, as the block (I, J) and transposed as (J, I), so that a
+// lane reads its row half at one base address + immediate offsets (one float of padding per row: the transposed stores walk
+// down a column and hit distinct banks).  Rows / columns 3 H .. 16 NTL - 1 are the tiles' zero padding.
 template <int H>
 struct GramTiles {
   static constexpr int N3 = 3 * H;                       // torque rows
   static constexpr int NTL = (N3 + 15) / 16;
   static constexpr int NU = NTL * (NTL + 1) / 2;
-  __host__ __device__ static constexpr int index(int I, int J) { return I * NTL - I * (I - 1) / 2 + (J - I); }   // I <= J
-  float t[NU][16][17];
+  static constexpr int LD = 16 * NTL + 1;
+  float g[16 * NTL][LD];
 };
 template <int H>
 struct alignas(16) Smem {
@@ -603,19 +606,27 @@ solve_body(const DevParams& P, const int B,
 #pragma unroll
         for (int a = 0; a < 3; ++a) sm.rr[j][ft][a] = fr[3 * ft + a] - xr[3 + a];         // REF:174-175
     }
+    if (l == 0) {
+      // Step 0's reference IS the feedback state (REF:63): its sines and cosines are the ones eul2rotm(x_fb[0:3]) needs for the
+      // body axes of the line-foot rows (REF:124-138, 193: roll = x[0], pitch = x[1], yaw = x[2]) -- three f64 sincos every lane
+      // used to repeat in front of the first factorisation.  Parked in the first row of Gu until phase B forms the rows.
+      sm.Gu[0][0] = sy; sm.Gu[0][1] = cy; sm.Gu[0][2] = sp; sm.Gu[0][3] = cp; sm.Gu[0][4] = sr; sm.Gu[0][5] = cr;
+    }
+  }
+  sync_workgroup();
+  // P_i = sum_{s <= i} R_inv,s (REF:160-171), entry q by lane q < 9: the H loads carry immediate offsets and are in flight together,
+  // the additions run in step order (every lane summing up to its own step cost one LDS round trip per step)
+  if (l < 9) {
+    RT rv[H], run = 0;
+#pragma unroll
+    for (int s = 0; s < H; ++s) rv[s] = sm.u.itv.Rv[s][l];
+#pragma unroll
+    for (int s = 0; s < H; ++s) { run += rv[s]; sm.CT[l][s] = run; }
   }
   sync_workgroup();
 #pragma unroll
-  for (int q = 0; q < 9; ++q) Pj[q] = 0;
-#pragma unroll 1
-  for (int s = 0; s <= j; ++s)
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Pj[q] += sm.u.itv.Rv[s][q];
+  for (int q = 0; q < 9; ++q) Pj[q] = sm.CT[q][j];
   if (valid) {
-    if (lead) {
-#pragma unroll
-      for (int q = 0; q < 9; ++q) sm.CT[q][j] = Pj[q];
-    }
     // free response s_j - x_ref[:, j]   (X_j is the state after step j)
     const RT j1 = (RT)(j + 1);
     RT e12[12];
@@ -743,42 +754,81 @@ solve_body(const DevParams& P, const int B,
     constexpr int N3 = GramTiles<H>::N3, NTL = GramTiles<H>::NTL, NU = GramTiles<H>::NU, NWV = Dims<H>::NWV;
     const int wv = l >> 6, ln = l & 63;
     const int kq = ln >> 4;                    // which of the four rows of M of a step this lane supplies
-    const double sqe[3] = {sqrt(2.0 * P.Q[0]), sqrt(2.0 * P.Q[1]), sqrt(2.0 * P.Q[2])};
-    const double sqw[3] = {P.dt * sqrt(2.0 * P.Q[6]), P.dt * sqrt(2.0 * P.Q[7]), P.dt * sqrt(2.0 * P.Q[8])};
+    const double sqe[3] = {P.sq_e[0], P.sq_e[1], P.sq_e[2]};      // (formed once on the host: six f64 square roots per lane otherwise)
+    const double sqw[3] = {P.sq_w[0], P.sq_w[1], P.sq_w[2]};
     const float* MeF = &sm.Me[0][0];
-    auto entry_e = [&](const int k, const int col) -> double {           // Euler rows: k = 3 (i - 1) + q
-      const int i = 1 + k / 3, q = k - 3 * (k / 3), jc = col / 3, ac = col - 3 * jc;
-      const bool ok = k < 3 * (H - 1) && col < N3 && jc < i;
-      const double v = (double)MeF[ok ? pair_index(i, jc) * 9 + 3 * q + ac : 0];
-      return ok ? v * (q == 0 ? sqe[0] : (q == 1 ? sqe[1] : sqe[2])) : 0.0;
-    };
-    auto entry_w = [&](const int k, const int col) -> double {           // angular-velocity rows: k = 3 i + q
-      const int i = k / 3, q = k - 3 * i, jc = col / 3, ac = col - 3 * jc;
-      const bool ok = k < 3 * H && col < N3 && jc <= i;
-      const double v = sm.Iw[ok ? jc : 0][3 * q + ac];
-      return ok ? v * (q == 0 ? sqw[0] : (q == 1 ? sqw[1] : sqw[2])) : 0.0;
-    };
+    // The row k of M a lane supplies advances by four per instruction: with k = 3 i' + q, k + 4 = 3 (i' + 1) + (q + 1), so the step
+    // and the axis are carried (q + 1, wrapped) instead of divided out, and what does not depend on the row -- the column's step
+    // and axis, the three scaled entries of I_w a column can contribute -- is formed once per tile.  (The first version divided k
+    // and the column by three for every entry: 550 cycles per instruction, 16.6 k / 38 k / 63 k cycles of the set-up at h = 10 / 16 / 20.)
+    const int kq3 = kq == 3 ? 1 : 0, kqq = kq == 3 ? 0 : kq;                 // kq = 3 kq3 + kqq
+    if (l == 64 * (NWV - 1)) {
+      // General rows of a foot block: G = Gu - mu * [rows 0..3, column 2].  Gu (the mu-free part) is the same for every step
+      // and foot of the instance and lives in LDS (plus its transpose); a lane keeps only the mu term it needs.  Formed here by
+      // one lane of the LAST wave, which has the fewest tiles below and would wait for the others at the barrier.
+      const RT s0 = sm.Gu[0][0], c0 = sm.Gu[0][1], s1 = sm.Gu[0][2], c1 = sm.Gu[0][3], s2 = sm.Gu[0][4], c2 = sm.Gu[0][5];
+      const float ey[3] = {(float)(c2 * s1 * s0 - s2 * c0), (float)(s2 * s1 * s0 + c2 * c0), (float)(c1 * s0)};
+      const float ez[3] = {(float)(c2 * s1 * c0 + s2 * s0), (float)(s2 * s1 * c0 - c2 * s0), (float)(c1 * c0)};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { sm.eyz[a] = ey[a]; sm.eyz[3 + a] = ez[a]; }
+      float G[6][6];
+      general_rows(0.f, ey, ez, (float)P.lh, (float)P.lt, G);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int b2 = 0; b2 < 6; ++b2) { sm.Gu[r][b2] = (RT)G[r][b2]; sm.GuT[b2][r] = (RT)G[r][b2]; }
+    }
 #pragma unroll 1
     for (int t = wv; t < NU; t += NWV) {       // (wave-uniform)
       int ti = 0, tj = t;                      // tile (ti <= tj) number t of the row-major list of the upper triangle
       while (tj >= NTL - ti) { tj -= NTL - ti; ++ti; }
       tj += ti;
       const int colA = 16 * ti + (ln & 15), colB = 16 * tj + (ln & 15);
+      const bool diag = ti == tj;
+      const int jA = colA / 3, aA = colA - 3 * jA, jB = colB / 3, aB = colB - 3 * jB;
+      const bool cA = colA < N3, cB = colB < N3;
       f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-      for (int k0 = 0; k0 < 3 * (H - 1); k0 += 4) {
-        const double av = entry_e(k0 + kq, colA);
-        const double bv = (ti == tj) ? av : entry_e(k0 + kq, colB);
-        acc = mfma_f64_16x16x4(av, bv, acc);
+      {                                         // Euler rows k = 3 (i - 1) + q: entry sqrt(2 Q_e[q]) Me[i][j][q][a] for j < i < H
+        int i = 1 + kq3, q = kqq, tri = kq3;     // tri = i (i - 1) / 2: the first (i, j) pair of step i in Me
+        const int offA = 9 * jA + aA, offB = 9 * jB + aB;
+#pragma unroll
+        for (int k0 = 0; k0 < 3 * (H - 1); k0 += 4) {
+          const double sc = q == 0 ? sqe[0] : (q == 1 ? sqe[1] : sqe[2]);
+          const int base = 9 * tri + 3 * q;
+          const bool okA = cA && i < H && jA < i, okB = cB && i < H && jB < i;
+          const double va = (double)MeF[okA ? base + offA : 0], vb = (double)MeF[okB ? base + offB : 0];
+          const double av = okA ? va * sc : 0.0;
+          const double bv = diag ? av : (okB ? vb * sc : 0.0);
+          acc = mfma_f64_16x16x4(av, bv, acc);
+          ++q; tri += i; ++i;
+          if (q == 3) { q = 0; tri += i; ++i; }
+        }
       }
-#pragma unroll 1
-      for (int k0 = 0; k0 < 3 * H; k0 += 4) {
-        const double av = entry_w(k0 + kq, colA);
-        const double bv = (ti == tj) ? av : entry_w(k0 + kq, colB);
-        acc = mfma_f64_16x16x4(av, bv, acc);
+      {
+        // Angular-velocity rows k = 3 i + q: entry sqrt(2 Q_w[q]) dt Iw_j[q][a] for j <= i < H -- the same three rows for every
+        // state step i the column has reached.  Their Gram matrix is the rank-3 product of those rows times the number of steps
+        // both columns have reached, H - max(j_A, j_B): ONE instruction (lane group q supplies row q, the fourth group zeros) and a
+        // count per accumulator entry, instead of 3 H / 4 instructions of masked repeats.
+        const int qw = kq == 3 ? 0 : kq;
+        const double ua = sm.Iw[cA ? jA : 0][3 * qw + aA] * (qw == 0 ? sqw[0] : (qw == 1 ? sqw[1] : sqw[2]));
+        const double ub = sm.Iw[cB ? jB : 0][3 * qw + aB] * (qw == 0 ? sqw[0] : (qw == 1 ? sqw[1] : sqw[2]));
+        const double av = (cA && kq < 3) ? ua : 0.0;
+        const double bv = diag ? av : ((cB && kq < 3) ? ub : 0.0);
+        const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+        const f64x4 accw = mfma_f64_16x16x4(av, bv, zero);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {             // accumulator entry v of this lane: tile row kq + 4 v, tile column ln & 15
+          const int jr = (16 * ti + kq + 4 * v) / 3;
+          const int cnt = H - (jr > jB ? jr : jB);      // (rows and columns past 3 H hold zeros: whatever the count)
+          acc[v] = fma((double)cnt, accw[v], acc[v]);
+        }
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) sm.u.gram.t[t][kq + 4 * v][ln & 15] = (float)acc[v];
+      for (int v = 0; v < 4; ++v) {              // accumulator entry v: tile row kq + 4 v, tile column ln & 15
+        const float gv = (float)acc[v];
+        sm.u.gram.g[16 * ti + kq + 4 * v][16 * tj + (ln & 15)] = gv;
+        if (!diag) sm.u.gram.g[16 * tj + (ln & 15)][16 * ti + kq + 4 * v] = gv;      // (wave-uniform; a diagonal tile holds both triangles)
+      }
     }
   }
   sync_workgroup();
@@ -786,16 +836,13 @@ solve_body(const DevParams& P, const int B,
     if (c < 3) {
       const int a = c;
       const int r = 3 * j + a;                  // this lane's torque row
+      const float* grow = &sm.u.gram.g[r][3 * jb];         // its column half: 3 HH consecutive entries
 #pragma unroll
       for (int jj = 0; jj < HH; ++jj) {
         const int j2 = jb + jj;
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          const int cb = 3 * j2 + b;
-          // tile (I <= J) holds the block as it is, the block (J, I) below the diagonal is its transpose
-          const int rI = r >> 4, cJ = cb >> 4, rr = r & 15, cc = cb & 15;
-          const bool tr = rI > cJ;
-          const float gv = sm.u.gram.t[GramTiles<H>::index(tr ? cJ : rI, tr ? rI : cJ)][tr ? cc : rr][tr ? rr : cc];
+          const float gv = grow[3 * jj + b];
           Grow[b * HH + jj] = gv;
           if (j2 == j && b == a) gdiag = gv;
           if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = (double)gv;     // view of the row (tests)
@@ -828,34 +875,13 @@ solve_body(const DevParams& P, const int B,
   if constexpr (PROF) t_setup = clock64() - t_start;
 
   // ------------------------------------------------------------------ C. constraint data (own foot)
-  // General rows of a foot block: G = Gu - mu * [rows 0..3, column 2].  Gu (the mu-free part) is the same
-  // for every step and foot of the instance and lives in LDS (plus its transpose); a lane keeps only
-  // the mu term it needs.
+  // (the mu-free general rows Gu / GuT and the body axes were stored by lane 0 in phase A)
   // (f32 values, widened at their points of use: as f64 they would hold twice the registers across the loop)
   float lb, ub, R2v;
   bool eqb;
   float cmu;                                  // -mu_f if this lane's variable is f_z (column 2 of the friction rows)
   float drf[3];                               // r_0 - r_1 of this step
   {
-    float ey[3], ez[3];                       // columns 1, 2 of R = eul2rotm(x_fb[0:3])  (REF:124-138, 193)
-    {
-      RT sr, cr, sp, cp, sy, cy;
-      sincos(xfb[0], &sr, &cr);
-      sincos(xfb[1], &sp, &cp);
-      sincos(xfb[2], &sy, &cy);
-      ey[0] = (float)(cy * sp * sr - sy * cr); ey[1] = (float)(sy * sp * sr + cy * cr); ey[2] = (float)(cp * sr);
-      ez[0] = (float)(cy * sp * cr + sy * sr); ez[1] = (float)(sy * sp * cr - cy * sr); ez[2] = (float)(cp * cr);
-    }
-    if (l == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { sm.eyz[a] = ey[a]; sm.eyz[3 + a] = ez[a]; }
-      float G[6][6];
-      general_rows(0.f, ey, ez, (float)P.lh, (float)P.lt, G);
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int b2 = 0; b2 < 6; ++b2) { sm.Gu[r][b2] = (RT)G[r][b2]; sm.GuT[b2][r] = (RT)G[r][b2]; }
-    }
     {
       const float cont = (float)contact[((size_t)inst * H + j) * 2 + f];
       const float muf = mu_in ? mu_in[((size_t)inst * H + j) * 2 + f] : (float)P.mu;

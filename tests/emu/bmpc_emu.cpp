@@ -268,6 +268,7 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.dt = p->dt; d.kv = p->kv; d.m = p->m; d.g = p->g; d.mu = p->mu;
   d.lt = p->lt - 0.01; d.lh = p->lh - 0.02; d.alpha = p->alpha;
   for (int i = 0; i < 12; ++i) { d.x_cmd[i] = p->x_cmd[i]; d.Q[i] = p->Q[i]; d.R2[i] = 2.0 * p->R[i]; }
+  for (int k = 0; k < 3; ++k) { d.sq_e[k] = std::sqrt(2.0 * p->Q[k]); d.sq_w[k] = p->dt * std::sqrt(2.0 * p->Q[6 + k]); }
   {
     double rmin = p->R[0];
     for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p->R[i]);

@@ -675,7 +675,7 @@ def test_bench_default_line_carries_the_contract_and_the_secondary_records():
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["config"]["baseline_config"] == 2 and line["config"]["not_converged"] == 0
     rf = line["roofline"]
     assert rf["frac"] == rf["frac_survey_formula"] and 0 < rf["frac"] < 1 and rf["kernel_ms"] <= line["ms_per_step"] * 1.02
-    assert rf["mfma_instructions_per_solve"] == 45 and rf["mfma_util"] > 0
+    assert rf["mfma_instructions_per_solve"] == 24 and rf["mfma_util"] > 0
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
     assert line["parity"]["max_rel_err_vs_oracle"] <= 1e-5 and line["parity"]["u0_max_rel_err"] <= 2e-5
     assert line["value_incl_pcie"]["bit_identical_to_device_path"] and line["value_incl_pcie"]["value"] > 0
