@@ -7,12 +7,13 @@ cfgs = sorted(int(os.path.basename(d)[3:]) for d in glob.glob(os.path.join(out, 
 H = {2: 10, 3: 16, 4: 10, 5: 20, 6: 32, 7: 40}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from biped_mpc_py_amd.synth import kernel_source_hash
-def counters(d, B=None):
+def counters(d, B=None, family=None):
     acc = {}
     fs = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for f in fs[-1:]:                            # the newest run only (gpurun_out accumulates every call's files)
         for r in csv.DictReader(open(f)):
-            if "solve_kernel" in r["Kernel_Name"] or "stage_kernel" in r["Kernel_Name"]:
+            # the kernel family of the line's path only (`--path best` times BOTH families before the timed region)
+            if (family or "solve_kernel") in r["Kernel_Name"] or (family is None and "stage_kernel" in r["Kernel_Name"]):
                 # whole-batch launches only (the host-pointer path solves a batch in chunks)
                 if B is not None and int(r["Grid_Size"]) != B * int(r["Workgroup_Size"]):
                     continue
@@ -26,7 +27,8 @@ for c in cfgs:
     except Exception:
         continue
     B = line["config"]["batch_per_gpu"]
-    fe, wr = counters(os.path.join(o, "pmc_fetch"), B), counters(os.path.join(o, "pmc_write"), B)
+    fam = "stage_kernel" if line["config"].get("path", "dense") == "stage" else "solve_kernel"
+    fe, wr = counters(os.path.join(o, "pmc_fetch"), B, fam), counters(os.path.join(o, "pmc_write"), B, fam)
     s = {"config": c, "batch": B, "horizon": H[c], "source": "profiles/%s_cfg%d_pmc_*.csv" % (tag, c),
          "path": line["config"].get("path", "dense"), "kernel_sha": kernel_source_hash()}
     if "FETCH_SIZE" in fe and "WRITE_SIZE" in wr:
@@ -39,7 +41,7 @@ for c in cfgs:
                      "FETCH_SIZE is NOT doubled: the gfx950 x2 correction is calibrated for 16-B/lane coalesced streams, this kernel reads dwords.")
     sq = {}
     for p in ("pmc_sq1", "pmc_sq2", "pmc_flops"):
-        sq.update({k: v[0] for k, v in counters(os.path.join(o, p), B).items()})
+        sq.update({k: v[0] for k, v in counters(os.path.join(o, p), B, fam).items()})
     s["sq_per_launch"] = sq
     if "SQ_INSTS_VALU_FLOPS_FP32" in sq:
         # the counters count flops per LANE of a wave instruction (FMA 2, packed FMA 4, ...), whatever the EXEC mask: x 64
