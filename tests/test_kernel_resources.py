@@ -75,8 +75,9 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
 def test_hessian_block_gemm_runs_on_the_matrix_cores(isa_text):
     """north_star: "MFMA used only for the dense horizon-block GEMMs inside the condensed Hessian".  The one such GEMM of the
     wrench-space form -- the torque block Gt_tt = M' M of the set-up -- is formed with v_mfma_f64_16x16x4_f64 in every dense
-    kernel (two accumulation loops: Euler rows, angular-velocity rows; f64: the row it fills is also the operator of the carried
-    gradient's increments), and nowhere else: the stage family never forms Gt."""
+    kernel (the Euler rows four per instruction, unrolled; the angular-velocity rows -- the same three at every state step -- as one
+    rank-3 instruction and a count; f64: the row it fills is also the operator of the carried gradient's increments), and nowhere
+    else: the stage family never forms Gt."""
     lines = isa_text.splitlines()
     seen = {}
     for i, ln in enumerate(lines):
