@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -52,6 +52,8 @@ class CParams(C.Structure):
         ("max_iter", C.c_int32), ("check_every", C.c_int32), ("adapt_start", C.c_int32),
         ("adapt_every", C.c_int32), ("max_refactor", C.c_int32), ("warm_adapt_start", C.c_int32),
         ("path", C.c_int32), ("penalty_mode", C.c_int32), ("rescue", C.c_int32), ("accel", C.c_int32),
+        ("adapt_early", C.c_int32), ("adapt_late", C.c_int32), ("adapt_busy", C.c_int32), ("adapt_flips", C.c_int32),
+        ("confirm_from", C.c_int32), ("reserved0", C.c_int32), ("kappa_confirm", C.c_double),
         ("kp", C.c_double * 9), ("kd", C.c_double * 9), ("swingHeight", C.c_double), ("hip_offset", C.c_double * 3),
     ]
 

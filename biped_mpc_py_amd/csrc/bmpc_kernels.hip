@@ -100,6 +100,10 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
 
 struct DevParams {
   int h, half, max_iter, check_every, adapt_start, adapt_every, max_refactor;
+  int adapt_early, adapt_late;                 // two-rate schedule: the first adapt_early re-classifications adapt_every apart, then adapt_late (0: one rate)
+  int adapt_busy, adapt_flips;                 // ... but adapt_busy after one that found more than adapt_flips rows in another class than the one before (0: off)
+  int confirm_from;                            // from re-classification number confirm_from + 1 on a row found in the same class as at the previous
+  float kappa_confirm;                         //   one moves by kappa_confirm instead of kappa (0: off)
   float r2min;                                 // 2 min R: the softest curvature of the problem
   double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
   double x_cmd[12], Q[12], R2[12], Iinv[9];    // R2 = 2 R;  Iinv = inverse body inertia
@@ -251,7 +255,7 @@ struct alignas(16) Smem {
   RT Gu[6][6];               // mu-free part of the general rows of a foot block, and its transpose
   RT GuT[6][6];
   float eyz[6];              // body y and z axes in the world frame (columns 1, 2 of eul2rotm(x_fb))
-  float red[2][H == 12 ? 6 : 11][Dims<H>::NWV];
+  float red[2][H == 12 ? 6 : 12][Dims<H>::NWV];
   float aag[H == 12 ? 0 : Dims<H>::NT][7];                   // secant extrapolation: a lane's state change (x, zb, zg, yb, yg, A x, gradient), kept from
                                                // the iteration before a stopping test, and over the test's reduction
                                                // (not at h = 12: the 3.8 KB would cost that kernel its fourth instance per CU)
@@ -1300,6 +1304,8 @@ solve_body(const DevParams& P, const int B,
   constexpr float FAR = 1.0e3f;
   int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
   while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
+  int n_adapt = 0;                             // re-classifications taken (the two-rate schedule: DevParams::adapt_early)
+  int prev_act = 0;                            // classes of this lane's rows at the previous re-classification (bit 0: box row, bit 1: general row)
   float res_p = 0.f, res_s = 0.f;
 
   // exact axg, bwl, gbl from x (exchange through LDS); all threads call
@@ -1631,26 +1637,38 @@ solve_body(const DevParams& P, const int B,
     // the workgroup; a re-classification always falls on a stopping test with the default periods, and the two
     // share ONE exchange: the residual statistics and the "some penalty moves" flag are reduced together.
     const bool adapt_now = (it == next_adapt);
-    if (adapt_now) next_adapt += P.adapt_every;
     const bool adapt_do = adapt_now && nfac <= P.max_refactor;
     // Damping: an instance that is still re-classifying after many rounds is cycling between active sets
     // (about one in a million at kappa = 20); smaller moves break the cycle (sqrt(kappa) after 10
     // factorisations, its square root after 16), where stopping the adaptation would leave hundreds of
     // plain-ADMM iterations.
-    auto reclassify = [&](float& nb, float& ng) {
+    // Confirmation (round 5): the rows that turn late are what keeps an instance re-classifying -- a row that changed class at
+    // iteration 60 walks its ladder at 70, 80, 90, three factorisations for a handful of rows, and those instances are the tail of a
+    // batch.  From re-classification number confirm_from + 1 on, a row found in the SAME class as at the previous one is taken at
+    // its word and moves by kappa_confirm (>= the length of a ladder: straight to its limit).  Not earlier: the classes of the first
+    // iterations are wrong for a fifth of the rows, and a row sent to a limit on their word has to walk all the way back.
+    auto reclassify = [&](float& nb, float& ng, int& act, const bool scheduled) {
       const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
       const bool actb = (zb <= (RT)lb || zb >= (RT)ub) && yb != (RT)0;
       const bool actg = (zg >= (RT)0) && yg != (RT)0;
+      act = (actb ? 1 : 0) | (actg ? 2 : 0);
+      const bool confirm = scheduled && P.kappa_confirm > 0.f && n_adapt >= P.confirm_from && n_adapt > 0 && nfac <= 10;   // (n_adapt: before this one)
+      const int same = confirm ? ~(act ^ prev_act) : 0;
+      const float kapb = (same & 1) ? P.kappa_confirm : kap, kapg = (same & 2) ? P.kappa_confirm : kap;
       // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
       const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-      nb = eqb ? P.rho_eq : (actb ? fminf(rvb * kap, hib) : fmaxf(rvb / kap, P.rho_lo));
-      ng = actg ? fminf(rvg * kap, hig) : fmaxf(rvg / kap, P.rho_lo);
+      nb = eqb ? P.rho_eq : (actb ? fminf(rvb * kapb, hib) : fmaxf(rvb / kapb, P.rho_lo));
+      ng = actg ? fminf(rvg * kapg, hig) : fmaxf(rvg / kapg, P.rho_lo);
     };
-    float chg = 0.f;
+    float chg = 0.f, nflip = 0.f;
+    int act_now = 0;
     if (adapt_do) {
       float nb, ng;
-      reclassify(nb, ng);
+      reclassify(nb, ng, act_now, true);
       chg = ((nb != rvb) | (ng != rvg)) ? 1.f : 0.f;
+      // rows in another class than at the previous re-classification (the clones repeat a real lane: not counted)
+      const int fl = act_now ^ prev_act;
+      nflip = (real && n_adapt > 0) ? (float)((fl & 1) + ((fl >> 1) & 1)) : 0.f;
     }
     // An inactive row whose penalty is still far above the floor follows at 1 - alpha c / rho per iteration, c the curvature
     // it sees -- 0.9999 against the soft curvature 2R: the residuals are then small because the steps are, not because the
@@ -1664,16 +1682,18 @@ solve_body(const DevParams& P, const int B,
     constexpr float SLOW_TOL = 1.0e-6f;
     constexpr float AA_GAMMA_MAX = 100.f;       // a secant step beyond the one of a 0.99 contraction is not trusted
     bool force_adapt = false;
+    float flips = 0.f;                          // rows of the instance that changed class since the previous re-classification
     if (check_now || adapt_do) {
       float v5[8] = {rp, rs, nz, nx, chg, slw, aa1, aa2};
       float u0v[3] = {0.f, 0.f, 0.f};           // step 0: residuals, norm, pull of its inactive rows
       if constexpr (AA) {
-        float v11[11] = {rp, rs, nz, nx, chg, slw, r0, nx0, slw0, aa1, aa2};
-        block_max_sum<NT, 9, 2, 3>(v11, sm.red[n_red & 1]);
+        float v12[12] = {rp, rs, nz, nx, chg, slw, r0, nx0, slw0, aa1, aa2, nflip};
+        block_max_sum<NT, 9, 3, 3>(v12, sm.red[n_red & 1]);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) v5[q] = v11[q];
-        u0v[0] = v11[6]; u0v[1] = v11[7]; u0v[2] = v11[8];
-        v5[6] = v11[9]; v5[7] = v11[10];
+        for (int q = 0; q < 6; ++q) v5[q] = v12[q];
+        u0v[0] = v12[6]; u0v[1] = v12[7]; u0v[2] = v12[8];
+        v5[6] = v12[9]; v5[7] = v12[10];
+        flips = v12[11];
       } else {
         float v6[6] = {rp, rs, nz, nx, chg, slw};
         block_max<NT, 6>(v6, sm.red[n_red & 1]);
@@ -1723,7 +1743,8 @@ solve_body(const DevParams& P, const int B,
       }
       if ((adapt_do && v5[4] > 0.f) || force_adapt) {   // (the new penalties are formed again rather than kept across the barrier)
         float nb, ng;
-        reclassify(nb, ng);
+        int a2;
+        reclassify(nb, ng, a2, adapt_do);
         rvb = nb; rvg = ng;
         irvb = (RT)1 / (RT)rvb; irvg = (RT)1 / (RT)rvg;
         need_factor = true;
@@ -1745,6 +1766,18 @@ solve_body(const DevParams& P, const int B,
         }
       }
       aa_have = false;
+    }
+    if (adapt_now) {
+      // The schedule (round 5).  The classes are found early -- of the 240 rows of a standing h = 10 instance 45 change class
+      // between iterations 10 and 20, 18 between 20 and 30, < 1 after 40 -- so the first adapt_early re-classifications come
+      // adapt_every apart; later ones adapt_late apart, or adapt_busy if this one still found more than adapt_flips rows in
+      // another class than the one before (the instances that keep turning are the tail of a batch: they are not made to wait).
+      if (adapt_do) prev_act = act_now;
+      ++n_adapt;
+      int period = P.adapt_every;
+      if (P.adapt_late > 0 && n_adapt >= P.adapt_early)
+        period = (P.adapt_busy > 0 && flips > (float)P.adapt_flips) ? P.adapt_busy : P.adapt_late;
+      next_adapt += period;
     }
     BMPC_STAMP(6)
     BMPC_DRAIN_LDS();                           // nothing in flight across the back edge (see sync_workgroup)

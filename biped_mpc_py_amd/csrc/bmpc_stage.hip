@@ -145,7 +145,7 @@ struct alignas(16) StageSmem {
   };
   union alignas(16) { Fac fac; Itv itv; } u;
   RT tot[2][5 * NW][12];       // block totals of the scans over the steps (double buffered)
-  float red[2][11][NW];        // reductions across the waves (nine maxima, two sums)
+  float red[2][12][NW];        // reductions across the waves (nine maxima, three sums)
   // block-diagonal part of K^-1 (see bmpc_kernels.hip): L~ = L E^-1 (acceleration space), Kn = {Ka^-1, T Ka^-1}.
   // (no G images as in the dense kernels: an instance's LDS decides how many instances share a CU, and the step d
   //  is exchanged once per iteration instead)
@@ -955,6 +955,8 @@ stage_body(const DevParams& P, const int B,
   constexpr float FAR = 1.0e3f;
   int next_adapt = P.adapt_every > 0 ? P.adapt_start : 0x7fffffff;
   while (next_adapt < 1) next_adapt += P.adapt_every;
+  int n_adapt = 0;                             // re-classifications taken (the two-rate schedule: DevParams::adapt_early)
+  int prev_act = 0;                            // classes of this lane's rows at the previous re-classification (bits 2 s: box row, 2 s + 1: general row of step slot s)
   float res_p = 0.f, res_s = 0.f;
   const RT idt_r = (RT)1 / dt, dtm = dt / (RT)P.m;
 
@@ -1397,14 +1399,22 @@ stage_body(const DevParams& P, const int B,
     BMPC_SSTAMP(3)
     // (penalty re-classification of step s from given (z, y) values: active rows move up by kappa towards their class
     //  ceiling, inactive ones down towards rho_lo; damped after many factorisations -- bmpc_kernels.hip)
-    auto reclassify_v = [&](int s, RT zbv, RT ybv, RT zgv, RT ygv, float& nb, float& ng) __attribute__((always_inline)) {
+    //  `scheduled`: a re-classification of the schedule (not the one the third stopping test forces): from number confirm_from + 1
+    //  on a row found in the same class as at the previous one moves by kappa_confirm -- bmpc_kernels.hip.  act2: the two classes.)
+    auto reclassify_v = [&](int s, RT zbv, RT ybv, RT zgv, RT ygv, float& nb, float& ng, int& act2, const bool scheduled) __attribute__((always_inline)) {
       const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
       const bool actb = (zbv <= (RT)lb[s] || zbv >= (RT)ub[s]) && ybv != (RT)0;
       const bool actg = (zgv >= (RT)0) && ygv != (RT)0;
+      act2 = (actb ? 1 : 0) | (actg ? 2 : 0);
+      const bool confirm = scheduled && P.kappa_confirm > 0.f && n_adapt >= P.confirm_from && n_adapt > 0 && nfac <= 10;   // (n_adapt: before this one)
+      const int same = confirm ? ~(act2 ^ (prev_act >> (2 * s))) : 0;
+      const float kapb = (same & 1) ? P.kappa_confirm : kap, kapg = (same & 2) ? P.kappa_confirm : kap;
       const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
-      nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kap, hib) : fmaxf(rvb[s] / kap, P.rho_lo));
-      ng = actg ? fminf(rvg[s] * kap, hig) : fmaxf(rvg[s] / kap, P.rho_lo);
+      nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kapb, hib) : fmaxf(rvb[s] / kapb, P.rho_lo));
+      ng = actg ? fminf(rvg[s] * kapg, hig) : fmaxf(rvg[s] / kapg, P.rho_lo);
     };
+    int act_now = 0;                          // the classes this re-classification finds (packed like prev_act)
+    float nflip = 0.f;                        // this lane's rows in another class than at the previous re-classification
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f, slw = 0.f;
     float r0 = 0.f, nx0 = 0.f, slw0 = 0.f;       // the rows of step 0 alone: the applied control has its own stopping test (bmpc_kernels.hip)
@@ -1505,8 +1515,12 @@ stage_body(const DevParams& P, const int B,
           aa2 = fmaf(d, d, aa2);
           if (adapt_next) {
             float nb, ng;
-            reclassify_v(s, znb, ybn, zng, ygn, nb, ng);
+            int a2;
+            reclassify_v(s, znb, ybn, zng, ygn, nb, ng, a2, true);
             chg_t = ((nb != rvb[s]) | (ng != rvg[s])) ? 1.f : chg_t;
+            act_now |= a2 << (2 * s);
+            const int fl = a2 ^ ((prev_act >> (2 * s)) & 3);
+            nflip += (lane_real && n_adapt > 0) ? (float)((fl & 1) + (fl >> 1)) : 0.f;
           }
         }
       } else {
@@ -1546,12 +1560,12 @@ stage_body(const DevParams& P, const int B,
     BMPC_SSTAMP(4)
     // --- stopping test and penalty re-classification (wave-uniform decisions; one wave: reductions by DPP alone)
     const bool adapt_now = (it == next_adapt);
-    if (adapt_now) next_adapt += P.adapt_every;
     const bool adapt_do = adapt_now && nfac <= P.max_refactor;
-    auto reclassify = [&](int s, float& nb, float& ng) __attribute__((always_inline)) {
-      reclassify_v(s, zb[s], yb[s], zg[s], yg[s], nb, ng);
+    auto reclassify = [&](int s, float& nb, float& ng, int& a2, const bool scheduled) __attribute__((always_inline)) {
+      reclassify_v(s, zb[s], yb[s], zg[s], yg[s], nb, ng, a2, scheduled);
     };
     bool force_adapt = false;
+    float flips = 0.f;                        // rows of the instance that changed class since the previous re-classification
     if (check_now || adapt_do) {
       float chg = 0.f;
       if (two_pass) {
@@ -1560,14 +1574,18 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
           float nb, ng;
-          reclassify(s, nb, ng);
+          int a2;
+          reclassify(s, nb, ng, a2, true);
           chg = (sreal[s] && ((nb != rvb[s]) | (ng != rvg[s]))) ? 1.f : chg;
+          act_now |= a2 << (2 * s);
+          const int fl = a2 ^ ((prev_act >> (2 * s)) & 3);
+          nflip += (sreal[s] && lane_real && n_adapt > 0) ? (float)((fl & 1) + (fl >> 1)) : 0.f;
         }
       }
       // (see bmpc_kernels.hip: the third stopping test -- the pull rho |z~ - z| of the inactive rows against the softest
       //  curvature; an instance that fails it re-classifies at once instead of stopping)
       constexpr float SLOW_TOL = 1.0e-6f;
-      float v5[11] = {rp, rs, nz, nx, chg, slw, aa1, aa2, r0, nx0, slw0};
+      float v5[12] = {rp, rs, nz, nx, chg, slw, aa1, aa2, r0, nx0, slw0, adapt_do ? nflip : 0.f};
 #pragma unroll
       for (int k = 0; k < 6; ++k) v5[k] = __uint_as_float(wave_umax(__float_as_uint(v5[k])));
 #pragma unroll
@@ -1576,12 +1594,13 @@ stage_body(const DevParams& P, const int B,
         v5[6] = wave_sum(v5[6]);
         v5[7] = wave_sum(v5[7]);
       }
+      if (adapt_do) v5[11] = wave_sum(v5[11]);  // (uniform) ... and the count of rows that changed class
       if constexpr (NW > 1) {                   // combine the waves (two buffers: a buffer is rewritten after another barrier)
         float (*red)[NW] = sm.red[n_red & 1];
         ++n_red;
         if (l == 0) {
 #pragma unroll
-          for (int k = 0; k < 11; ++k) red[k][wv] = v5[k];
+          for (int k = 0; k < 12; ++k) red[k][wv] = v5[k];
         }
         sync_workgroup();
 #pragma unroll
@@ -1593,13 +1612,15 @@ stage_body(const DevParams& P, const int B,
           v5[k] = __uint_as_float(m);
         }
 #pragma unroll
-        for (int k = 6; k < 8; ++k) {
+        for (int k = 6; k < 12; ++k) {
+          if (k >= 8 && k < 11) continue;
           float a2 = red[k][0];
 #pragma unroll
           for (int w2 = 1; w2 < NW; ++w2) a2 += red[k][w2];
           v5[k] = a2;
         }
       }
+      flips = v5[11];
       if (check_now) {
         res_p = v5[0];
         res_s = v5[1];
@@ -1635,12 +1656,21 @@ stage_body(const DevParams& P, const int B,
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
           float nb, ng;
-          reclassify(s, nb, ng);
+          int a2;
+          reclassify(s, nb, ng, a2, adapt_do);
           rvb[s] = nb; rvg[s] = ng;
           irvb[s] = (RT)1 / (RT)nb; irvg[s] = (RT)1 / (RT)ng;
         }
         need_factor = true;
       }
+    }
+    if (adapt_now) {                          // the schedule: bmpc_kernels.hip
+      if (adapt_do) prev_act = act_now;
+      ++n_adapt;
+      int period = P.adapt_every;
+      if (P.adapt_late > 0 && n_adapt >= P.adapt_early)
+        period = (P.adapt_busy > 0 && flips > (float)P.adapt_flips) ? P.adapt_busy : P.adapt_late;
+      next_adapt += period;
     }
     BMPC_SSTAMP(5)
     BMPC_DRAIN_LDS();

@@ -45,7 +45,8 @@ class Biped:
 
 # solver knobs (bmpc_default_params): overridable through solver_options
 SOLVER_FIELDS = ("rho", "rho_eq_scale", "rho_lo", "rho_hi_f", "rho_hi_m", "kappa", "alpha", "eps_pri", "eps_dua",
-                 "max_iter", "check_every", "adapt_start", "adapt_every", "max_refactor", "warm_adapt_start", "path", "penalty_mode", "rescue", "accel")
+                 "max_iter", "check_every", "adapt_start", "adapt_every", "max_refactor", "warm_adapt_start", "path", "penalty_mode", "rescue", "accel",
+                 "adapt_early", "adapt_late", "adapt_busy", "adapt_flips", "confirm_from", "kappa_confirm")
 
 # bmpc_params.path (include/bmpc.h enum bmpc_path)
 PATH_AUTO, PATH_DENSE, PATH_STAGE = 0, 1, 2

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 9
+#define BMPC_ABI_VERSION 10
 
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
@@ -104,9 +104,9 @@ typedef struct bmpc_params {
   double eps_pri, eps_dua;   /* relative stopping tolerances */
   int32_t max_iter;          /* iteration cap (default 1000 at h <= 12, else 1500; worst seen at the reference's weights: 240 / 315) */
   int32_t check_every;       /* stopping test period */
-  int32_t adapt_start;       /* first penalty re-classification (default 10; 20 at h = 20) */
-  int32_t adapt_every;       /* re-classification period (0 = never; default 10 at h = 10, 20 at h = 16, 20: the
-                                period follows the cost of a factorisation relative to an iteration) */
+  int32_t adapt_start;       /* first penalty re-classification (default 5 at h <= 12, 10 at h = 14 .. 18 and h > 20, 20 at h = 20) */
+  int32_t adapt_every;       /* re-classification period (0 = never; default 5 at h <= 12 -- see adapt_early --, 20 at h = 14 .. 20,
+                                10 beyond: the period follows the cost of a factorisation relative to an iteration) */
   int32_t max_refactor;      /* cap on re-factorisations per instance (then plain ADMM with the penalties reached); default 60:
                                 a decade or two away from the reference's weights 1 instance in ~300 keeps re-classifying
                                 for up to 60 rounds (damped moves) and then converges; at the reference's weights <= 18 */
@@ -136,6 +136,24 @@ typedef struct bmpc_params {
                                 reduction the stopping test already pays for).  Both families (not the dense kernel of h = 12 nor
                                 the stage kernel of h = 22 / 24: no LDS / registers for it): 5-7 % fewer iterations and
                                 factorisations up to h = 20, 2-5 % beyond, 1-4 % less kernel time.  Same fixed point. */
+  int32_t adapt_early;       /* two-rate re-classification schedule (ABI 10): the first `adapt_early` re-classifications -- the one at
+                                adapt_start included -- are `adapt_every` iterations apart, the later ones `adapt_late`.  The active set
+                                is found in the first ~20 iterations (45 of 240 rows change class between iterations 10 and 20,
+                                < 1 after 40), so early re-classifications are worth a factorisation each and late ones mostly
+                                walk a few rows along their ladder.  Default at h <= 12: 5 / 5 / 3 / 20 (iterations 5, 10, 15, 35,
+                                55 ...); 0 (or adapt_late = 0): every re-classification adapt_every apart (the schedule of ABI <= 9) */
+  int32_t adapt_late;
+  int32_t adapt_busy;        /* ... but `adapt_busy` iterations after a (late) re-classification that still found more than `adapt_flips` of
+                                the instance's rows in another class than the one before: the instances that keep turning are the
+                                tail of a batch and are not made to wait.  0: always adapt_late.  Default at h <= 12: 10, 1.
+                                (Not on the kernels that carry no secant step -- dense h = 12, stage h = 22 / 24: always adapt_late.) */
+  int32_t adapt_flips;
+  int32_t confirm_from;      /* confirmation: from re-classification number confirm_from + 1 on, a row found in the SAME class as at the
+                                previous re-classification moves by kappa_confirm instead of kappa (>= the length of a ladder: straight
+                                to its ceiling / floor) -- a row that turns late otherwise costs three more factorisations walking
+                                there.  Default at h <= 12: 3, 400; kappa_confirm = 0: off */
+  int32_t reserved0;
+  double kappa_confirm;
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
   double kp[9], kd[9];       /* REF:30-31, row-major 3x3 */
   double swingHeight;        /* REF:32 */

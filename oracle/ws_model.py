@@ -54,8 +54,12 @@ class Params:
         self.rho_hi_m = 100.0
         self.adapt_start = 10
         self.adapt_every = 10
-        self.adapt_growth = 1.0
-        self.use_fraction = False
+        self.adapt_early = 0       # two-rate schedule (bmpc_params.adapt_early / adapt_late): the first adapt_early re-classifications
+        self.adapt_late = 0        # adapt_every apart, the later ones adapt_late; 0: one rate
+        self.adapt_busy = 0        # ... or adapt_busy after one that found more than adapt_flips rows in another class (0: off)
+        self.adapt_flips = 1
+        self.kappa_confirm = 0.0   # a row found in the same class as at the previous re-classification moves by this (0: off),
+        self.confirm_from = 0      # from re-classification number confirm_from + 1 on
         self.blocks_hi = True
         self.kappa = 20.0
         self.alpha = 1.6
@@ -264,6 +268,8 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
         hi_ds[[3, 4, 5, 10, 11]] = ds[1]
         hi = np.where(other, np.minimum(hi, hi_ds), hi)                    # (B,h,2,12)
     rv = np.where(eq, rho_eq, rho0).astype(dtp)                            # (B,h,2,12)
+    if getattr(P, "rv_init", None) is not None:                            # (experiments: start from given penalties)
+        rv = np.where(eq, rho_eq, np.asarray(P.rv_init)).astype(dtp)
     R2 = 2 * P.R.astype(dtp)
     Rblk = np.stack([np.concatenate([R2[0:3], R2[6:9]]), np.concatenate([R2[3:6], R2[9:12]])])  # (2,6)
     Wf = np.zeros((B, h, 2, 6, 6), dtp)                                    # per foot [[r]x I; I 0]
@@ -279,10 +285,10 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
     fac = lambda rv_: _factor(P, Gt, A, rv_, Rblk, Wf, Nf, pdt, blk=(rdt if P.blocks_hi else pdt), ric=ric)
     L, Na, V = fac(rv)
     n_factor = np.ones(B, int)
-    next_adapt, gap = P.adapt_start, P.adapt_every
-    cnt_act = np.zeros(rv.shape, int)
-    cnt_len = 0
-    act_prev = None
+    next_adapt = np.full(B, P.adapt_start if P.adapt_every else 10 ** 9)       # per instance, like the kernels' counters
+    n_adapt = np.zeros(B, int)
+    act_prev = np.zeros(rv.shape, bool)
+    seen_act = np.zeros(B, bool)
     alpha = rdt.type(P.alpha)
     x = np.zeros((B, h, 2, 6), rdt)
     z = np.zeros((B, h, 2, 12), rdt)
@@ -364,37 +370,43 @@ def solve_batch(P, x_fb, foot, contact, phase, x_cmd=None, mu=None, dtype=np.flo
         y = np.where(keep, yn, y)
         if not active.any():
             break
-        cnt_act += (((z <= lr) | (z >= ur)) & (y != 0))
-        cnt_len += 1
-        if P.adapt_every and (it + 1) == next_adapt:
-            gap = max(int(round(gap * P.adapt_growth)), 1)
-            next_adapt += gap
+        due = active & ((it + 1) == next_adapt) if P.adapt_every else np.zeros(B, bool)
+        if due.any():
+            # per-instance schedule (the kernels: every workgroup has its own counters).  Two rates: the first adapt_early
+            # re-classifications adapt_every apart, the later ones adapt_late (bmpc_params.adapt_early / adapt_late)
+            n_adapt = n_adapt + due
             act = ((z <= lr) | (z >= ur)) & (y != 0)
-            if P.use_fraction:
-                full = cnt_act >= cnt_len
-                none = cnt_act == 0
-                rnew = np.where(eq, rho_eq, np.where(full, hi, np.where(none, dt_(P.rho_lo), rho0))).astype(dtp)
-            elif P.kappa:
+            flips = np.where(seen_act, (act != act_prev).reshape(B, -1).sum(1), 0)       # rows whose class changed since the instance's last re-classification
+            late = (getattr(P, "adapt_late", 0) > 0) & (n_adapt >= getattr(P, "adapt_early", 0))
+            # (... but adapt_busy after a re-classification that still found more than adapt_flips rows in another class)
+            busy = (flips > getattr(P, "adapt_flips", 0)) & (getattr(P, "adapt_busy", 0) > 0)
+            period = np.where(late, np.where(busy, getattr(P, "adapt_busy", 0), getattr(P, "adapt_late", 0)), P.adapt_every)
+            if P.kappa:
                 # damping as in the kernel: sqrt(kappa) after 10 factorisations, its square root after 16
-                kap = np.where(n_factor <= 10, P.kappa, np.where(n_factor <= 16, P.kappa ** 0.5, P.kappa ** 0.25))
-                kap = kap.astype(dtp)[:, None, None, None]
-                rvc = np.clip(rv, dt_(P.rho_lo), hi)            # (rows coming back from the finishing penalties)
+                kap = np.where(n_factor <= 10, P.kappa, np.where(n_factor <= 16, P.kappa ** 0.5, P.kappa ** 0.25)).astype(dtp)[:, None, None, None]
+                kc = getattr(P, "kappa_confirm", 0)
+                if kc:
+                    # a row found in the same class as at the instance's previous re-classification is taken at its word: it
+                    # moves by kappa_confirm (>= the distance to its limit: straight there) instead of walking its ladder
+                    conf = (act == act_prev) & (seen_act & (n_adapt > getattr(P, "confirm_from", 0)))[:, None, None, None] & (n_factor <= 10)[:, None, None, None]
+                    kap = np.where(conf, dt_(kc), kap)
+                rvc = np.clip(rv, dt_(P.rho_lo), hi)
                 up = np.minimum(rvc * kap, hi)
                 dn = np.maximum(rvc / kap, dt_(P.rho_lo))
                 rnew = np.where(eq, rho_eq, np.where(act, up, dn)).astype(dtp)
-                fin = getattr(P, "finish", None)
-                if fin:
-                    # finishing move: an active set that did not change since the last re-classification is taken for
-                    # the final one and gets near-hard / near-free penalties
-                    same = (act == act_prev).reshape(B, -1).all(1) if act_prev is not None else np.zeros(B, bool)
-                    rfin = np.where(eq, rho_eq, np.where(act, hi * dt_(fin[1]), dt_(fin[0]))).astype(dtp)
-                    rnew = np.where(same[:, None, None, None], rfin, rnew)
-                    act_prev = act.copy()
+                rhook = getattr(P, "rnew_hook", None)          # (experiments: any rule; gets the state it may look at)
+                if rhook is not None:
+                    rnew = rhook(P, dict(it=it + 1, n_factor=n_factor, rv=rv, rnew=rnew, act=act, eq=eq, hi=hi, z=z, y=y, l=lr, u=ur,
+                                         rho_eq=rho_eq, x=x, due=due, flips=flips)).astype(dtp)
             else:
                 rnew = np.where(eq, rho_eq, np.where(act, hi, dt_(P.rho_lo))).astype(dtp)
-            cnt_act[:] = 0
-            cnt_len = 0
-            changed = (rnew != rv).reshape(B, -1).any(1) & active & (n_factor <= P.max_refactor)
+            phook = getattr(P, "period_hook", None)            # (experiments: the next period from what this re-classification saw)
+            if phook is not None:
+                period = phook(P, dict(it=it + 1, n_adapt=n_adapt, flips=flips, moved=(rnew != rv).reshape(B, -1).sum(1), period=period, n_factor=n_factor))
+            next_adapt = np.where(due, next_adapt + period, next_adapt)
+            act_prev = np.where(due[:, None, None, None], act, act_prev)
+            seen_act = seen_act | due
+            changed = due & (rnew != rv).reshape(B, -1).any(1) & (n_factor <= P.max_refactor)
             if changed.any():
                 if getattr(P, "trace", None) is not None:           # (tools: how many steps a re-factorisation really touches)
                     nst = (rnew != rv).any(axis=(2, 3)).sum(1)

@@ -265,6 +265,9 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   std::memset(&d, 0, sizeof(d));
   d.h = p->h; d.half = p->half; d.max_iter = p->max_iter; d.check_every = p->check_every;
   d.adapt_start = p->adapt_start; d.adapt_every = p->adapt_every; d.max_refactor = p->max_refactor;
+  d.adapt_early = p->adapt_early; d.adapt_late = p->adapt_late;
+  d.adapt_busy = p->adapt_busy; d.adapt_flips = p->adapt_flips;
+  d.confirm_from = p->confirm_from; d.kappa_confirm = (float)p->kappa_confirm;
   d.dt = p->dt; d.kv = p->kv; d.m = p->m; d.g = p->g; d.mu = p->mu;
   d.lt = p->lt - 0.01; d.lh = p->lh - 0.02; d.alpha = p->alpha;
   for (int i = 0; i < 12; ++i) { d.x_cmd[i] = p->x_cmd[i]; d.Q[i] = p->Q[i]; d.R2[i] = 2.0 * p->R[i]; }
