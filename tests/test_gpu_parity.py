@@ -733,8 +733,10 @@ def test_closed_loop_rollout_and_warm_start(gait):
         assert np.allclose(t.cpu().numpy(), t0 + K * mpc.dt)
         s.close()
     assert np.array_equal(out[True][0], out[False][0])             # the first period starts cold either way
-    # measured: 0.60x in double support, 0.84x while the contact schedule advances every period
-    assert out[True][1:].mean() < (0.7 if gait == "standing" else 0.95) * out[False][1:].mean()
+    # measured: 0.60x in double support, 0.84x while the contact schedule advances every period -- of the
+    # cold counts of round 4; the round-5 schedule took 20 % off a COLD solve (35.6 instead of 44.2 iterations here) and 4 % off a
+    # warm one (25.4 instead of 26.5): 0.71x
+    assert out[True][1:].mean() < (0.78 if gait == "standing" else 0.95) * out[False][1:].mean()
 
 
 def test_reference_generators_dropin():
