@@ -17,6 +17,7 @@ EXPORTS = (
     "bmpc_default_params",
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
     "bmpc_solve_batch", "bmpc_solve_batch_f64", "bmpc_solve_batch_device", "bmpc_synchronize",
+    "bmpc_host_io", "bmpc_solve_batch_io",
     "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
     "bmpc_foot_position_world", "bmpc_foot_position_world_device",
     "bmpc_low_level_control", "bmpc_low_level_control_device",
@@ -28,6 +29,12 @@ EXPORTS = (
 class CGait(C.Structure):
     """`bmpc_gait` of include/bmpc.h."""
     _fields_ = [("period", C.c_int32), ("offset", C.c_int32 * 2), ("duty", C.c_int32 * 2)]
+
+
+class CHostViews(C.Structure):
+    """`bmpc_host_views` of include/bmpc.h: the arrays of a handle's page-locked I/O block."""
+    _fields_ = [(n, C.c_void_p) for n in ("x_fb", "foot", "contact", "phase", "x_cmd", "mu", "controls", "states",
+                                           "iters", "residuals", "status", "nfactor")]
 
 
 class BmpcError(RuntimeError):
@@ -111,6 +118,8 @@ def load():
     lib.bmpc_solve_batch_f64.argtypes = [vp, ip] + ptrs14
     lib.bmpc_solve_batch_device.argtypes = [vp, ip] + ptrs14 + [vp]
     lib.bmpc_synchronize.argtypes = [vp]
+    lib.bmpc_host_io.argtypes = [vp, ip, ip, ip, ip, C.POINTER(CHostViews)]
+    lib.bmpc_solve_batch_io.argtypes = [vp, ip]
     lib.bmpc_debug_assemble.argtypes = [vp, ip] + [vp] * 10
     lib.bmpc_debug_set_profile.argtypes = [vp, vp]
     lib.bmpc_foot_position_world.argtypes = [vp, ip, vp, vp, vp]

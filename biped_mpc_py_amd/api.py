@@ -91,6 +91,7 @@ class BatchSolver:
         self.cparams = cparams
 
     def close(self):
+        self._io, self._io_key = None, None        # (views of the handle's page-locked block: gone with the handle)
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.bmpc_destroy(self._h)
             self._h = C.c_void_p()
@@ -143,6 +144,59 @@ class BatchSolver:
             _ptr(controls), _ptr(states), _ptr(iters), _ptr(resid), _ptr(status), _ptr(nfactor)))
         info = dict(iters=iters, status=status, nfactor=nfactor, residuals=resid)
         return states, controls, info
+
+    def _io_views(self, B, with_x_cmd, with_mu, with_states):
+        """NumPy views of the handle's page-locked I/O block laid out for batches of B (`bmpc_host_io`); cached per layout."""
+        key = (B, bool(with_x_cmd), bool(with_mu), bool(with_states))
+        if getattr(self, "_io_key", None) == key:
+            return self._io
+        v = _lib.CHostViews()
+        _lib.check(self._lib.bmpc_host_io(self._h, B, int(key[1]), int(key[2]), int(key[3]), C.byref(v)))
+        h = self.h
+
+        def view(addr, dtype, shape):
+            if not addr:
+                return None
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * n).from_address(addr), dtype=dtype).reshape(shape)
+
+        self._io = dict(x_fb=view(v.x_fb, np.float32, (B, 12)), foot=view(v.foot, np.float32, (B, 6)),
+                        contact=view(v.contact, np.uint8, (B, h, 2)), phase=view(v.phase, np.int32, (B,)),
+                        x_cmd=view(v.x_cmd, np.float32, (B, 12)), mu=view(v.mu, np.float32, (B, h, 2)),
+                        controls=view(v.controls, np.float64, (B, h, 12)), states=view(v.states, np.float64, (B, h, 13)),
+                        iters=view(v.iters, np.int32, (B,)), residuals=view(v.residuals, np.float32, (B, 2)),
+                        status=view(v.status, np.int32, (B,)), nfactor=view(v.nfactor, np.int32, (B,)))
+        self._io_key = key
+        return self._io
+
+    def solve_inplace(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_states=True):
+        """Host arrays in, results IN the solver's own buffers: what a control loop that keeps its arrays wants.  The inputs are
+        converted (fp32) straight into the handle's page-locked I/O block, cross PCIe in one copy, ONE launch solves the batch and
+        the kernels store `states` / `controls` into the block's host arrays, already widened to the reference's fp64
+        (REF:300-304) -- no device-to-host copy and no unpacking pass (`bmpc_host_io` / `bmpc_solve_batch_io`).  Returns
+        (states | None, controls, info) as VIEWS of that block: valid until the next `solve_inplace` of this solver (copy what
+        must outlive it).  Same values as `solve`, bit for bit."""
+        h = self.h
+        xf = np.asarray(x_fb)
+        B = xf.size // 12
+        io = self._io_views(B, x_cmd is not None, mu is not None, want_states)
+        np.copyto(io["x_fb"], xf.reshape(B, 12), casting="same_kind")
+        np.copyto(io["foot"], np.asarray(foot).reshape(B, 6), casting="same_kind")
+        cc = np.asarray(contact)
+        if cc.dtype == np.uint8 and cc.size == B * h * 2:          # (the fast path: one pass for the 0 / 1 check, one for the copy)
+            if cc.size and cc.max() > 1:
+                raise ValueError("contact entries must be 0 or 1")
+            np.copyto(io["contact"], cc.reshape(B, h, 2))
+        else:
+            np.copyto(io["contact"], _contact_u8(cc, B, h))
+        np.copyto(io["phase"], np.asarray(phase).reshape(B), casting="same_kind")
+        if x_cmd is not None:
+            np.copyto(io["x_cmd"], np.asarray(x_cmd).reshape(B, 12), casting="same_kind")
+        if mu is not None:
+            np.copyto(io["mu"], np.asarray(mu).reshape(B, h, 2), casting="same_kind")
+        _lib.check(self._lib.bmpc_solve_batch_io(self._h, B))
+        info = dict(iters=io["iters"], status=io["status"], nfactor=io["nfactor"], residuals=io["residuals"])
+        return io["states"], io["controls"], info
 
     def assemble(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_matrices=True):
         """Assembly stage only (parity tests, reference generators): x_ref (B,h,12), foot_ref (B,h,6) and -- with

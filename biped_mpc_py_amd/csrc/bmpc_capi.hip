@@ -194,7 +194,10 @@ struct PinnedBuf {
     if (bytes <= n) return hipSuccess;
     if (p) (void)hipHostFree(p);
     p = nullptr; n = 0;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault);
+    // (mapped: the kernels of the host-pointer entry points store their results straight into this memory)
+    unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
+    if (const char* ev = std::getenv("BMPC_PIN_FLAGS")) flags = (unsigned)std::strtoul(ev, nullptr, 0);   // (experiments)
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), bytes, flags);
     if (e == hipSuccess) n = bytes;
     return e;
   }
@@ -236,6 +239,24 @@ struct bmpc_handle_s {
   DevBuf<char> dev_in, dev_out;
   hipStream_t cstream[HOST_CHUNKS] = {nullptr, nullptr, nullptr};
   hipEvent_t cev[HOST_CHUNKS] = {nullptr, nullptr, nullptr};
+  hipEvent_t cev_own = nullptr;     // what the handle's own stream held when a host-pointer call began: the chunk streams wait for it
+  // the chunking of the host-pointer entry points, fixed at creation (BMPC_HOST_CUTS = "a,b" with 0 < a <= b <= 1, or "1": one
+  // chunk; anything else is ignored) and the diagnostics switch BMPC_HOST_TIMING
+  int host_chunks = HOST_CHUNKS;
+  double host_cut[HOST_CHUNKS + 1] = {0.0, 0.55, 0.85, 1.0};
+  bool host_timing = false;
+  // the handle's I/O block (bmpc_host_io / bmpc_solve_batch_io): page-locked host memory, mapped into the device's address
+  // space -- the caller writes its inputs there, the kernels store the fp64 results there
+  PinnedBuf io_in, io_out;
+  DevBuf<char> io_dev;
+  DevBuf<double> io_states;         // fp64 states of a batch in HBM, on their way to the I/O block by copy engine
+  hipEvent_t cev_in = nullptr;      // the I/O block's inputs have arrived
+  struct IoLayout {
+    int B = 0;
+    bool x_cmd = false, mu = false, states = false;
+    size_t i_xfb = 0, i_foot = 0, i_phase = 0, i_xcmd = 0, i_mu = 0, i_con = 0, in_bytes = 0;
+    size_t o_u = 0, o_s = 0, o_it = 0, o_st = 0, o_nf = 0, o_rs = 0, out_bytes = 0;
+  } io;
   DevBuf<float> x_fb, foot, x_cmd, mu, controls, states, resid;
   DevBuf<uint8_t> contact;
   DevBuf<int32_t> phase, iters, status, nfactor;
@@ -269,9 +290,9 @@ template <int H>
 int launch_h(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
              const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
              int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-             hipStream_t st, const int32_t* order) {
+             hipStream_t st, const int32_t* order, double* c64, double* s64) {
   constexpr int NT = bmpc::Dims<H>::NT;
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order, nullptr};
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order, nullptr, c64, s64};
   if (hd->warm_on && !dbg.assemble_only) {
     const size_t need = (size_t)B * NT * 6;
     if (need > hd->warm.n) hd->warm_valid = false;          // growing the buffer loses the stored state
@@ -298,8 +319,8 @@ template <int NP, int NW>
 int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                  const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
                  int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-                 hipStream_t st, const int32_t* order, const int32_t* rescue_status = nullptr) {
-  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order, rescue_status};
+                 hipStream_t st, const int32_t* order, const int32_t* rescue_status, double* c64, double* s64) {
+  bmpc::WarmArgs warm = {nullptr, 0, 0, 0, 1.f, 0, dbg.assemble_only ? nullptr : order, rescue_status, c64, s64};
   if (hd->warm_on && !dbg.assemble_only && !rescue_status) {   // (a rescue pass starts cold: the stored state is the dense family's)
     const size_t need = (size_t)B * (5 * NP * NW) * 12 * 6;  // [B][5 NP NW][12][6] doubles
     if (need > hd->warm.n) hd->warm_valid = false;
@@ -325,10 +346,10 @@ int launch_stage(bmpc_handle hd, int B, const float* x_fb, const float* foot, co
 int launch_stage_any(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                      const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
                      int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-                     hipStream_t st, const int32_t* order, const int32_t* rescue_status) {
+                     hipStream_t st, const int32_t* order, const int32_t* rescue_status, double* c64, double* s64) {
   // compiled per (steps a lane owns, waves per instance): bmpc::stage_steps_per_lane / stage_waves
   switch (10 * bmpc::stage_waves(hd->dev.h) + bmpc::stage_steps_per_lane(hd->dev.h)) {
-#define BMPC_CASE(NN, WW) case 10 * WW + NN: return launch_stage<NN, WW>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order, rescue_status);
+#define BMPC_CASE(NN, WW) case 10 * WW + NN: return launch_stage<NN, WW>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order, rescue_status, c64, s64);
     BMPC_CASE(2, 1) BMPC_CASE(3, 1) BMPC_CASE(4, 1) BMPC_CASE(5, 1) BMPC_CASE(3, 2) BMPC_CASE(4, 2)
 #undef BMPC_CASE
     default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
@@ -338,12 +359,12 @@ int launch_stage_any(bmpc_handle hd, int B, const float* x_fb, const float* foot
 int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const uint8_t* contact,
            const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,
            int32_t* iters, float* resid, int32_t* status, int32_t* nfactor, const bmpc::DebugOut& dbg,
-           hipStream_t st, const int32_t* order) {
+           hipStream_t st, const int32_t* order, double* c64 = nullptr, double* s64 = nullptr) {
   const bool dense_views = dbg.assemble_only && (dbg.Gt || dbg.qt);      // Gt, qt only exist on the dense path
   if (hd->path == BMPC_PATH_STAGE && !(dense_views && dense_horizon(hd->dev.h))) {
     if (dense_views) return fail(BMPC_ERR_INVALID, "Gt / qt views exist for h <= 20 only (h=%d never forms them)", hd->dev.h);
     return launch_stage_any(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st,
-                            order, nullptr);
+                            order, nullptr, c64, s64);
   }
   // Dense family.  With the rescue pass on, the instances whose status is not 0 afterwards are solved again by the
   // stage-structured kernel of the same horizon (f32 Riccati recursion instead of the f32 explicit inverse: it does not
@@ -356,7 +377,7 @@ int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const ui
   }
   int rc = BMPC_ERR_INVALID;
   switch (hd->dev.h) {
-#define BMPC_CASE(HH) case HH: rc = launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order); break;
+#define BMPC_CASE(HH) case HH: rc = launch_h<HH>(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, dbg, st, order, c64, s64); break;
     BMPC_DENSE_HORIZONS(BMPC_CASE)
 #undef BMPC_CASE
     default: return fail(BMPC_ERR_INVALID, "unsupported horizon h=%d", hd->dev.h);
@@ -365,7 +386,7 @@ int launch(bmpc_handle hd, int B, const float* x_fb, const float* foot, const ui
   bmpc::DebugOut quiet = dbg;
   quiet.prof = nullptr;                        // the cycle stamps stay those of the first solve
   return launch_stage_any(hd, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, resid, status, nfactor, quiet, st,
-                          order, status);
+                          order, status, c64, s64);
 }
 
 // NULL is HIP's null (legacy default) stream, like every hip* call; BMPC_STREAM_OWN the handle's own stream
@@ -498,7 +519,17 @@ int bmpc_create(bmpc_handle* out, const bmpc_params* params, int device, int max
     // lowest, so that the workgroup dispatcher serves the chunks in order and the first results leave early
     int least = 0, greatest = 0;
     if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (std::getenv("BMPC_HOST_TIMING")) std::fprintf(stderr, "[bmpc host path] stream priorities: least %d greatest %d\n", least, greatest);
+    h->host_timing = std::getenv("BMPC_HOST_TIMING") != nullptr;
+    if (h->host_timing) std::fprintf(stderr, "[bmpc host path] stream priorities: least %d greatest %d\n", least, greatest);
+    if (const char* ev = std::getenv("BMPC_HOST_CUTS")) {          // (experiments: "0.5,0.8", "0.6" for two chunks, "1" for one)
+      double a = 1.0, b = 1.0;
+      const int k = std::sscanf(ev, "%lf,%lf", &a, &b);
+      if (k == 1 && a >= 1.0) h->host_chunks = 1;
+      else if (k == 1 && a > 0.0) { h->host_chunks = 2; h->host_cut[1] = a; h->host_cut[2] = 1.0; }
+      else if (k == 2 && a > 0.0 && a <= b && b <= 1.0) { h->host_cut[1] = a; h->host_cut[2] = b; }
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->cev_own, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->cev_in, hipEventDisableTiming);
     for (int c = 0; c < bmpc_handle_s::HOST_CHUNKS && e == hipSuccess; ++c) {
       int prio = greatest + c;                   // (numerically lower = more urgent)
       if (prio > least) prio = least;
@@ -529,7 +560,11 @@ int bmpc_destroy(bmpc_handle h) {
     if (h->cstream[c]) { (void)hipStreamSynchronize(h->cstream[c]); (void)hipStreamDestroy(h->cstream[c]); }
     if (h->cev[c]) (void)hipEventDestroy(h->cev[c]);
   }
+  if (h->cev_own) (void)hipEventDestroy(h->cev_own);
+  if (h->cev_in) (void)hipEventDestroy(h->cev_in);
+  h->io_states.release();
   h->pin_in.release(); h->pin_out.release(); h->dev_in.release(); h->dev_out.release();
+  h->io_in.release(); h->io_out.release(); h->io_dev.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -557,21 +592,23 @@ int bmpc_get_params(bmpc_handle h, bmpc_params* out) {
 }
 
 // one solve launch with the dispatch order given explicitly (roll-outs use their own, the handle's stays untouched)
+// (ev: which of the handle's timing events this launch records -- bit 0: ev0 before it, bit 1: ev1 after it; a batch that goes
+//  out in chunks records ev0 before its first kernel and ev1 after its last, so bmpc_last_kernel_ms spans them all.
+//  c64 / s64: fp64 output arrays instead of controls / states, see bmpc::WarmArgs)
 static int solve_device_ordered(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                                 const int32_t* phase, const float* x_cmd, const float* mu, float* controls,
                                 float* states, int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor,
-                                void* stream, const int32_t* order) {
-  int rc = check_common(h, B, x_fb, foot, contact, phase, controls);
+                                void* stream, const int32_t* order, int ev = 3, double* c64 = nullptr, double* s64 = nullptr) {
+  int rc = check_common(h, B, x_fb, foot, contact, phase, c64 ? static_cast<const void*>(c64) : static_cast<const void*>(controls));
   if (rc != BMPC_OK) return rc;
   if (B == 0) return BMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = pick_stream(h, stream);
   bmpc::DebugOut dbg = {nullptr, nullptr, nullptr, nullptr, h->prof_dev, 0};
-  HIP_TRY(hipEventRecord(h->ev0, st));
-  rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st, order);
+  if (ev & 1) HIP_TRY(hipEventRecord(h->ev0, st));
+  rc = launch(h, B, x_fb, foot, contact, phase, x_cmd, mu, controls, states, iters, residuals, status, nfactor, dbg, st, order, c64, s64);
   if (rc != BMPC_OK) return rc;
-  HIP_TRY(hipEventRecord(h->ev1, st));
-  h->timed = true;
+  if (ev & 2) { HIP_TRY(hipEventRecord(h->ev1, st)); h->timed = true; }
   return BMPC_OK;
 }
 
@@ -589,11 +626,14 @@ int bmpc_solve_batch_device(bmpc_handle h, int B, const float* x_fb, const float
 //   * per chunk the inputs are packed into one pinned block and cross in ONE copy; outputs come back one packed block;
 //   * the batch is split into up to HOST_CHUNKS contiguous chunks, each launched on its own stream (descending priority:
 //     the dispatcher serves chunk 0's workgroups first), followed on that stream by the chunk's device-to-host copy: the
-//     results of chunk c cross PCIe, and are unpacked (widened to fp64) by the calling thread, while chunks c + 1 .. still
-//     solve.  Only the last chunk's copy and unpacking are exposed.
+//     results of chunk c cross PCIe, and are unpacked (widened to fp64) into the caller's pageable arrays by the calling thread,
+//     while chunks c + 1 .. still solve.  Only the last chunk's copy and unpacking are exposed.
+//     (A caller that can take its results in the handle's own page-locked block has no unpacking at all: bmpc_solve_batch_io.)
 // The kernels' arithmetic does not depend on the position in a batch, so the results are bit-identical to a single launch.
 // Warm start, a dispatch order and the profile buffer index by the instance's position in the whole batch: with any of them
 // set the batch goes out as one chunk.
+// Ordering: the chunk streams wait for what was queued on the handle's own stream before the call (a device-pointer solve on
+// BMPC_STREAM_OWN, its warm-start state), and the call returns with every chunk complete.
 }  // extern "C"  (a template cannot have C linkage)
 
 namespace {
@@ -609,25 +649,17 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
   if (B == 0) return BMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)B, H = (size_t)h->dev.h;
-  const bool timing = std::getenv("BMPC_HOST_TIMING") != nullptr;     // (diagnostics: where a host-pointer call spends its time)
+  const bool timing = h->host_timing;                                 // (diagnostics: where a host-pointer call spends its time)
   auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = timing ? now() : 0.0;
   double t_wait = 0, t_unpack = 0, t_last_wait = 0, t_last_unpack = 0;
   // ---- chunks: contiguous, one per stream priority the device offers (MI355X: three; chunks that share a priority are
-  // served round robin and finish together), the later ones smaller: the last chunk's copy and unpacking are the exposed part,
-  // and a chunk's unpacking (~1/3 of its solve time) has to fit before the next chunk arrives.  Measured (4096 instances,
-  // h = 10): chunks ready 540 / 720 / 890 us after the call, the call returns ~60 us after the last kernel ends.
+  // served round robin and finish together), the later ones smaller: the last chunk's unpacking is the exposed part,
+  // and a chunk's unpacking (~1/3 of its solve time) has to fit before the next chunk arrives.
   const bool whole = h->warm_on || h->order || h->prof_dev;
   int nchunk = whole ? 1 : (int)(n / 512);
-  nchunk = nchunk < 1 ? 1 : (nchunk > bmpc_handle_s::HOST_CHUNKS ? bmpc_handle_s::HOST_CHUNKS : nchunk);
-  double kCut4[bmpc_handle_s::HOST_CHUNKS + 1] = {0.0, 0.55, 0.85, 1.0};
-  if (const char* e = std::getenv("BMPC_HOST_CUTS")) {          // (experiments: "0.5,0.8", or "1" for one chunk)
-    double a = 1.0, b = 1.0;
-    const int k = std::sscanf(e, "%lf,%lf", &a, &b);
-    if (k == 1 && a >= 1.0) nchunk = 1;
-    else if (k == 1) { nchunk = nchunk < 2 ? nchunk : 2; kCut4[1] = a; kCut4[2] = 1.0; }
-    else if (k == 2) { kCut4[1] = a; kCut4[2] = b; }
-  }
+  nchunk = nchunk < 1 ? 1 : (nchunk > h->host_chunks ? h->host_chunks : nchunk);
+  const double* kCut4 = h->host_cut;
   // per-instance bytes of a chunk's packed blocks.  in: x_fb, foot, phase [, x_cmd] [, mu], contact;
   // out: controls [, states], iters, status, nfactor, residuals (every sub-array starts 16-byte aligned)
   const size_t in_per = (12 + 6 + 1 + (x_cmd ? 12 : 0) + (mu ? 2 * H : 0)) * 4 + 2 * H;
@@ -637,8 +669,20 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
   HIP_TRY(h->dev_in.ensure(in_bytes));
   HIP_TRY(h->pin_out.ensure(out_bytes));
   HIP_TRY(h->dev_out.ensure(out_bytes));
+  // what the handle's own stream holds (a device-pointer solve on BMPC_STREAM_OWN, the warm-start state it writes) comes first
+  HIP_TRY(hipEventRecord(h->cev_own, h->stream));
   struct Chunk { size_t lo, nb, off, o_u, o_s, o_it, o_st, o_nf, o_rs, bytes; } ck[bmpc_handle_s::HOST_CHUNKS];
   size_t off = 0, ioff = 0;
+  int issued = 0;                               // chunks whose work is queued (an error below waits for them before returning)
+  auto bail = [&](int code) {
+    for (int c = 0; c < issued; ++c) (void)hipStreamSynchronize(h->cstream[c]);   // their copies still read pin_in / write pin_out
+    return code;
+  };
+#define HOST_TRY(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return bail(fail(BMPC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)));       \
+  } while (0)
   for (int c = 0; c < nchunk; ++c) {
     Chunk& k = ck[c];
     k.lo = nchunk >= 2 ? (size_t)(n * kCut4[c]) : 0;
@@ -668,7 +712,9 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
     k.bytes = align16(k.o_rs + k.nb * 2 * 4);
     off += k.bytes;
     hipStream_t st = h->cstream[c];
-    HIP_TRY(hipMemcpyAsync(din, pin, i_bytes, hipMemcpyHostToDevice, st));
+    HOST_TRY(hipStreamWaitEvent(st, h->cev_own, 0));
+    issued = c + 1;
+    HOST_TRY(hipMemcpyAsync(din, pin, i_bytes, hipMemcpyHostToDevice, st));
     char* dout = h->dev_out.p + k.off;
     rc = solve_device_ordered(h, (int)k.nb, reinterpret_cast<const float*>(din + i_xfb), reinterpret_cast<const float*>(din + i_foot),
                               reinterpret_cast<const uint8_t*>(din + i_con), reinterpret_cast<const int32_t*>(din + i_phase),
@@ -676,17 +722,21 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
                               mu ? reinterpret_cast<const float*>(din + i_mu) : nullptr,
                               reinterpret_cast<float*>(dout + k.o_u), states ? reinterpret_cast<float*>(dout + k.o_s) : nullptr,
                               reinterpret_cast<int32_t*>(dout + k.o_it), reinterpret_cast<float*>(dout + k.o_rs),
-                              reinterpret_cast<int32_t*>(dout + k.o_st), reinterpret_cast<int32_t*>(dout + k.o_nf), st, h->order);
-    if (rc != BMPC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(h->pin_out.p + k.off, dout, k.bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(h->cev[c], st));
+                              reinterpret_cast<int32_t*>(dout + k.o_st), reinterpret_cast<int32_t*>(dout + k.o_nf), st, h->order,
+                              (c == 0 ? 1 : 0) | (c == nchunk - 1 ? 2 : 0));
+    if (rc != BMPC_OK) return bail(rc);
+    // (the copy engine moves a chunk at ~50 GB/s while the later chunks solve; stores of the kernels themselves into mapped host
+    //  memory sustain ~8.6 GB/s on MI355X -- measured, round 5 -- which a 4096-instance batch's 4 MB would just fit under, with
+    //  nothing to spare)
+    HOST_TRY(hipMemcpyAsync(h->pin_out.p + k.off, dout, k.bytes, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipEventRecord(h->cev[c], st));
   }
   const double t_issued = timing ? now() : 0.0;
   // ---- unpack chunk by chunk, as each arrives
   for (int c = 0; c < nchunk; ++c) {
     const Chunk& k = ck[c];
     const double tw0 = timing ? now() : 0.0;
-    HIP_TRY(hipEventSynchronize(h->cev[c]));
+    HOST_TRY(hipEventSynchronize(h->cev[c]));
     const double tw1 = timing ? now() : 0.0;
     t_wait += tw1 - tw0; t_last_wait = tw1 - tw0;
     if (timing) std::fprintf(stderr, "[bmpc host path]   chunk %d ready %.0f us after the call began (waited %.0f)\n", c, tw1 - t_begin, tw1 - tw0);
@@ -703,15 +753,124 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
     if (residuals) std::memcpy(residuals + k.lo * 2, src + k.o_rs, k.nb * 2 * 4);
     if (timing) { const double tu = now() - tw1; t_unpack += tu; t_last_unpack = tu; }
   }
+#undef HOST_TRY
   if (timing)
     std::fprintf(stderr, "[bmpc host path] B %d chunks %d: pack + issue %.0f us, waiting %.0f us (last chunk %.0f), unpack %.0f us (last chunk %.0f), total %.0f us\n",
                  B, nchunk, t_issued - t_begin, t_wait, t_last_wait, t_unpack, t_last_unpack, now() - t_begin);
   return BMPC_OK;
 }
 
+// layout of the handle's I/O block for a batch (bmpc_host_io): inputs | outputs, every array 64-byte aligned
+inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
 }  // namespace
 
 extern "C" {
+
+int bmpc_host_io(bmpc_handle h, int B, int with_x_cmd, int with_mu, int with_states, bmpc_host_views* out) {
+  if (!h || !out) return fail(BMPC_ERR_INVALID, "null argument");
+  if (B < 1 || B > h->max_batch) return fail(BMPC_ERR_INVALID, "batch %d outside [1, max_batch=%d]", B, h->max_batch);
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B, H = (size_t)h->dev.h;
+  bmpc_handle_s::IoLayout& L = h->io;
+  L.B = 0;
+  L.i_xfb = 0;
+  L.i_foot = align64(L.i_xfb + n * 12 * 4);
+  L.i_phase = align64(L.i_foot + n * 6 * 4);
+  L.i_xcmd = align64(L.i_phase + n * 4);
+  L.i_mu = align64(L.i_xcmd + (with_x_cmd ? n * 12 * 4 : 0));
+  L.i_con = align64(L.i_mu + (with_mu ? n * H * 2 * 4 : 0));
+  L.in_bytes = align64(L.i_con + n * H * 2);
+  L.o_u = 0;
+  L.o_s = align64(L.o_u + n * H * 12 * 8);
+  L.o_it = align64(L.o_s + (with_states ? n * H * 13 * 8 : 0));
+  L.o_st = align64(L.o_it + n * 4);
+  L.o_nf = align64(L.o_st + n * 4);
+  L.o_rs = align64(L.o_nf + n * 4);
+  L.out_bytes = align64(L.o_rs + n * 2 * 4);
+  // (the handle's own stream may still read the old block: a re-allocation waits for it)
+  if (L.in_bytes > h->io_in.n || L.out_bytes > h->io_out.n) HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->io_in.ensure(L.in_bytes));
+  HIP_TRY(h->io_out.ensure(L.out_bytes));
+  HIP_TRY(h->io_dev.ensure(L.in_bytes));
+  L.B = B; L.x_cmd = with_x_cmd != 0; L.mu = with_mu != 0; L.states = with_states != 0;
+  char* in = h->io_in.p;
+  char* o = h->io_out.p;
+  out->x_fb = reinterpret_cast<float*>(in + L.i_xfb);
+  out->foot = reinterpret_cast<float*>(in + L.i_foot);
+  out->phase = reinterpret_cast<int32_t*>(in + L.i_phase);
+  out->x_cmd = with_x_cmd ? reinterpret_cast<float*>(in + L.i_xcmd) : nullptr;
+  out->mu = with_mu ? reinterpret_cast<float*>(in + L.i_mu) : nullptr;
+  out->contact = reinterpret_cast<uint8_t*>(in + L.i_con);
+  out->controls = reinterpret_cast<double*>(o + L.o_u);
+  out->states = with_states ? reinterpret_cast<double*>(o + L.o_s) : nullptr;
+  out->iters = reinterpret_cast<int32_t*>(o + L.o_it);
+  out->status = reinterpret_cast<int32_t*>(o + L.o_st);
+  out->nfactor = reinterpret_cast<int32_t*>(o + L.o_nf);
+  out->residuals = reinterpret_cast<float*>(o + L.o_rs);
+  return BMPC_OK;
+}
+
+int bmpc_solve_batch_io(bmpc_handle h, int B) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  const bmpc_handle_s::IoLayout& L = h->io;
+  if (B < 1 || B != L.B) return fail(BMPC_ERR_INVALID, "bmpc_solve_batch_io: batch %d, but the I/O block is laid out for %d (bmpc_host_io)", B, L.B);
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)B, H = (size_t)h->dev.h;
+  char* din = h->io_dev.p;
+  char* o = h->io_out.p;
+  // How the results cross PCIe (MI355X, measured in round 5): stores of a kernel into mapped host memory sustain ~8.6 GB/s, the
+  // copy engine ~50 GB/s.  A 4096-instance batch returns 3.9 MB of fp64 controls and 4.3 MB of fp64 states in 0.8 ms: the
+  // controls (and the per-instance counters) go straight from the kernels' epilogues into the host arrays -- free below that
+  // rate --, the states are stored in HBM and follow by copy engine, chunk by chunk on the chunk streams of the host-pointer
+  // path, so that only the last chunk's copy (15 % of the states) is exposed.  Everything through the kernels: +0.12 ms.
+  const bool whole = h->warm_on || h->order || h->prof_dev || !L.states;     // (one chunk: everything straight from the kernel)
+  int nchunk = whole ? 1 : (int)(n / 512);
+  nchunk = nchunk < 1 ? 1 : (nchunk > h->host_chunks ? h->host_chunks : nchunk);
+  if (L.states) HIP_TRY(h->io_states.ensure(n * H * 13));
+  HIP_TRY(hipEventRecord(h->cev_own, h->stream));              // what the handle's own stream holds comes first
+  int issued = 0;
+  auto bail = [&](int code) {
+    for (int c = 0; c < issued; ++c) (void)hipStreamSynchronize(h->cstream[c]);
+    return code;
+  };
+#define IO_TRY(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return bail(fail(BMPC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)));       \
+  } while (0)
+  for (int c = 0; c < nchunk; ++c) {
+    const size_t lo = nchunk >= 2 ? (size_t)(n * h->host_cut[c]) : 0;
+    const size_t nb = (c == nchunk - 1 ? n : (size_t)(n * h->host_cut[c + 1])) - lo;
+    hipStream_t st = h->cstream[c];
+    IO_TRY(hipStreamWaitEvent(st, h->cev_own, 0));
+    issued = c + 1;
+    if (c == 0) {                               // ONE copy in, for the whole batch
+      IO_TRY(hipMemcpyAsync(din, h->io_in.p, L.in_bytes, hipMemcpyHostToDevice, st));
+      IO_TRY(hipEventRecord(h->cev_in, st));
+    } else {
+      IO_TRY(hipStreamWaitEvent(st, h->cev_in, 0));
+    }
+    // (the last chunk's states go the way of the controls: nothing is left to copy when its kernel ends, and 15 % of the
+    //  states on top of the controls stay well below what the kernels' own stores sustain)
+    const bool by_copy = L.states && c < nchunk - 1;
+    double* s64 = !L.states ? nullptr : (by_copy ? h->io_states.p + lo * H * 13 : reinterpret_cast<double*>(o + L.o_s) + lo * H * 13);
+    int rc = solve_device_ordered(h, (int)nb, reinterpret_cast<const float*>(din + L.i_xfb) + lo * 12, reinterpret_cast<const float*>(din + L.i_foot) + lo * 6,
+                                  reinterpret_cast<const uint8_t*>(din + L.i_con) + lo * H * 2, reinterpret_cast<const int32_t*>(din + L.i_phase) + lo,
+                                  L.x_cmd ? reinterpret_cast<const float*>(din + L.i_xcmd) + lo * 12 : nullptr,
+                                  L.mu ? reinterpret_cast<const float*>(din + L.i_mu) + lo * H * 2 : nullptr, nullptr, nullptr,
+                                  reinterpret_cast<int32_t*>(o + L.o_it) + lo, reinterpret_cast<float*>(o + L.o_rs) + lo * 2,
+                                  reinterpret_cast<int32_t*>(o + L.o_st) + lo, reinterpret_cast<int32_t*>(o + L.o_nf) + lo, st, h->order,
+                                  (c == 0 ? 1 : 0) | (c == nchunk - 1 ? 2 : 0),
+                                  reinterpret_cast<double*>(o + L.o_u) + lo * H * 12, s64);
+    if (rc != BMPC_OK) return bail(rc);
+    if (by_copy) IO_TRY(hipMemcpyAsync(reinterpret_cast<double*>(o + L.o_s) + lo * H * 13, s64, nb * H * 13 * sizeof(double), hipMemcpyDeviceToHost, st));
+    IO_TRY(hipEventRecord(h->cev[c], st));
+  }
+  for (int c = 0; c < nchunk; ++c) IO_TRY(hipEventSynchronize(h->cev[c]));
+#undef IO_TRY
+  return BMPC_OK;
+}
 
 int bmpc_solve_batch(bmpc_handle h, int B, const float* x_fb, const float* foot, const uint8_t* contact,
                      const int32_t* phase, const float* x_cmd, const float* mu, float* controls, float* states,

@@ -136,6 +136,12 @@ struct WarmArgs {
   // rescue pass or null (stage-structured kernels only): a status array of an earlier solve of the same batch; the
   // instances it reports solved (0) are left alone, the others are solved again from a cold start
   const int32_t* rescue_status;
+  // fp64 outputs or null: `controls` / `states` are then stored here, widened ((double)(float) value: exactly the fp32 result), and
+  // the fp32 arrays are not touched.  What the host-pointer entry points use: the arrays are page-locked host memory mapped
+  // into the device's address space, so the results cross PCIe as the instances finish, in the dtype REF:300-304 returns --
+  // no device-to-host copy and no widening pass after the kernel.
+  double* controls64;
+  double* states64;
 };
 
 template <int H>
@@ -1789,16 +1795,23 @@ solve_body(const DevParams& P, const int B,
   }
 
   // ------------------------------------------------------------------ F. outputs (REF:300-304)
+  // Staged in LDS (the block-diagonal factors are dead: every wave is past the last barrier of the loop) and written out by
+  // consecutive lanes, 8 / 16 bytes each: whole lines instead of the 4-byte pieces a lane's own variable makes.  For the
+  // device arrays that is HBM traffic at the algorithmic bytes; for the host-mapped fp64 arrays of the host-pointer entry
+  // points (WarmArgs::controls64) it is what lets the results cross PCIe while the batch runs -- written lane by lane they
+  // cost a 4096-instance launch 0.10 ms (round 5, measured).
+  float* ost = reinterpret_cast<float*>(&sm.LG[0]);              // [12 H] controls, then [13 H] states
+  static_assert(sizeof(sm.LG) >= 25 * H * sizeof(float), "output staging does not fit the factor blocks");
+  const bool want_states = states || warm.states64;
   if (real) {
-    float* uo = controls + ((size_t)inst * H + j) * 12;
     const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
-    uo[pos] = (float)xo;
+    ost[j * 12 + pos] = (float)xo;
   }
-  if (states) {
+  if (want_states) {
     // the wrench of the final x is still in bwT (exact: every way out of the loop rebuilds it at its last
     // stopping test, and no factorisation -- which shares that LDS region -- follows); X_i = s_i + Gam_t b
     if (real) {
-      float* so = states + ((size_t)inst * H + j) * 13;
+      float* so = ost + 12 * H + j * 13;
       const int i = j;
       if (c < 3) {
         const int a = c;
@@ -1829,6 +1842,27 @@ solve_body(const DevParams& P, const int B,
         so[hf == 0 ? 3 + a : 9 + a] = (float)p;
       }
       if (c == 0 && hf == 0) so[12] = 1.0f;
+    }
+  }
+  sync_workgroup();
+  {
+    // pairs of values per lane (H is even: 6 H pairs of controls, 13 H / 2 of states; an instance's arrays start 8-byte
+    // aligned as fp32 and 16-byte aligned as fp64 when the caller's arrays do)
+    const float2* o2 = reinterpret_cast<const float2*>(ost);
+    constexpr int NC2 = 6 * H, NS2 = 13 * H / 2;
+    if (warm.controls64) {
+      double2* cu = reinterpret_cast<double2*>(warm.controls64 + (size_t)inst * H * 12);
+      for (int q = l; q < NC2; q += NT) { const float2 v = o2[q]; cu[q] = double2{(double)v.x, (double)v.y}; }
+    } else {
+      float2* cu = reinterpret_cast<float2*>(controls + (size_t)inst * H * 12);
+      for (int q = l; q < NC2; q += NT) cu[q] = o2[q];
+    }
+    if (warm.states64) {
+      double2* su = reinterpret_cast<double2*>(warm.states64 + (size_t)inst * H * 13);
+      for (int q = l; q < NS2; q += NT) { const float2 v = o2[NC2 + q]; su[q] = double2{(double)v.x, (double)v.y}; }
+    } else if (states) {
+      float2* su = reinterpret_cast<float2*>(states + (size_t)inst * H * 13);
+      for (int q = l; q < NS2; q += NT) su[q] = o2[NC2 + q];
     }
   }
   if (PROF && dbg.prof && l == 0) {

@@ -1691,14 +1691,16 @@ stage_body(const DevParams& P, const int B,
   for (int s = 0; s < NP; ++s) {
     if (!(sreal[s] && lane_real)) continue;
     const Step j = BMPC_STEP(s);
-    float* uo = controls + ((size_t)inst * H + j) * 12;
     const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
-    uo[pos] = (float)xo[s];
-    if (states) {
-      float* so = states + ((size_t)inst * H + j) * 13;
+    // (fp64 output arrays: the fp32 result widened, bmpc_kernels.hip WarmArgs::controls64)
+    if (warm.controls64) warm.controls64[((size_t)inst * H + j) * 12 + pos] = (double)(float)xo[s];
+    else controls[((size_t)inst * H + j) * 12 + pos] = (float)xo[s];
+    if (states || warm.states64) {
+      const size_t sbase = ((size_t)inst * H + j) * 13;
       const RT xrn = (j == 0) ? xfb_n : ((n < 6 && xc_n6 != (RT)0) ? xfb_n + xc_n6 * ((RT)j * dt) : xc_n);      // x_ref[n, j]
-      so[n] = (float)(xrn + err[s]);
-      if (n == 0) so[12] = 1.0f;
+      const float sv = (float)(xrn + err[s]);
+      if (warm.states64) { warm.states64[sbase + n] = (double)sv; if (n == 0) warm.states64[sbase + 12] = 1.0; }
+      else { states[sbase + n] = sv; if (n == 0) states[sbase + 12] = 1.0f; }
     }
   }
   if (PROF && dbg.prof && lt == 0) {

@@ -26,8 +26,9 @@ extern "C" {
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
  * launch is ordered after the caller's earlier work on that stream and before its later work, exactly
- * like a hip* call.  BMPC_STREAM_OWN selects the handle's private (non-blocking) stream, the one the
- * host-pointer entry points use. */
+ * like a hip* call.  BMPC_STREAM_OWN selects the handle's private (non-blocking) stream: the one bmpc_debug_assemble and the
+ * host-pointer low-level entries run on.  bmpc_solve_batch / bmpc_solve_batch_f64 / bmpc_solve_batch_io run their chunks on
+ * three prioritised streams of their own, which wait for whatever the handle's own stream held when the call began. */
 #define BMPC_STREAM_OWN ((void*)(intptr_t)-1)
 
 enum bmpc_status {
@@ -215,16 +216,49 @@ int bmpc_solve_batch(bmpc_handle h, int B,
  * values are the fp32 results of bmpc_solve_batch, exactly (float -> double is exact).
  *
  * Both host-pointer entries stage through page-locked memory owned by the handle (one packed block in, one packed block per
- * chunk out) and split a batch of >= 1024 instances into up to 3 contiguous chunks (55 / 30 / 15 %) on streams of descending priority: a
- * chunk's device-to-host copy and unpacking overlap the later chunks' solves.  Results do not depend on the chunking (the
- * kernels' arithmetic does not depend on the position in a batch).  With warm start, a dispatch order or the profile buffer
- * set the batch goes out as one chunk.
+ * chunk out) and split a batch of >= 1024 instances into up to 3 contiguous chunks (55 / 30 / 15 %) on streams of descending
+ * priority: a chunk's device-to-host copy and its unpacking into the caller's pageable arrays overlap the later chunks' solves.  Results do not depend on the chunking (the kernels' arithmetic does not depend on the
+ * position in a batch).  With warm start, a dispatch order or the profile buffer set the batch goes out as one chunk.
+ * bmpc_last_kernel_ms afterwards: from the start of the first chunk's kernel to the end of the last one's.
  */
 int bmpc_solve_batch_f64(bmpc_handle h, int B,
                          const float* x_fb, const float* foot, const uint8_t* contact,
                          const int32_t* phase, const float* x_cmd, const float* mu,
                          double* controls, double* states,
                          int32_t* iters, float* residuals, int32_t* status, int32_t* nfactor);
+
+/*
+ * The handle's I/O block (ABI 10): host arrays the caller fills and reads IN PLACE -- what a control loop that keeps its buffers
+ * wants, and the fastest way across PCIe.  The block is page-locked host memory owned by the handle and mapped into the device's
+ * address space: the inputs cross in ONE copy, and the results arrive in the host arrays already widened to the fp64
+ * REF:300-304 returns (the widening happens in the kernels' epilogues; the values are the fp32 results of bmpc_solve_batch,
+ * exactly) with no unpacking pass: `controls` and the per-instance counters are stored by the kernels straight into the host
+ * arrays, `states` follow by copy engine chunk by chunk (up to 3 chunks on prioritised streams, as in bmpc_solve_batch; the last
+ * chunk's states go the way of the controls) -- on MI355X a kernel's own stores into host memory sustain ~8.6 GB/s, the copy
+ * engine ~50 GB/s, and a 4096-instance batch returns 8.2 MB in 0.8 ms.
+ *   bmpc_host_io(h, B, with_x_cmd, with_mu, with_states, &views)   lays the block out for batches of exactly B instances and
+ *       returns the array pointers (layouts as in bmpc_solve_batch; x_cmd / mu / states NULL unless asked for).  The views stay
+ *       valid until the next bmpc_host_io of this handle or bmpc_destroy.
+ *   bmpc_solve_batch_io(h, B)   solves what the input views hold; synchronous: on return the output views hold the results.
+ * Ordered after whatever the handle's own stream held when the call began (BMPC_STREAM_OWN launches).  Warm start, dispatch
+ * order and the rescue pass apply as for bmpc_solve_batch_device (with warm start or a dispatch order: one chunk).
+ */
+typedef struct bmpc_host_views {
+  float* x_fb;        /* [B][12] */
+  float* foot;        /* [B][6] */
+  uint8_t* contact;   /* [B][h][2] */
+  int32_t* phase;     /* [B] */
+  float* x_cmd;       /* [B][12] or NULL */
+  float* mu;          /* [B][h][2] or NULL */
+  double* controls;   /* [B][h][12] */
+  double* states;     /* [B][h][13] or NULL */
+  int32_t* iters;     /* [B] */
+  float* residuals;   /* [B][2] */
+  int32_t* status;    /* [B] */
+  int32_t* nfactor;   /* [B] */
+} bmpc_host_views;
+int bmpc_host_io(bmpc_handle h, int B, int with_x_cmd, int with_mu, int with_states, bmpc_host_views* out);
+int bmpc_solve_batch_io(bmpc_handle h, int B);
 
 /*
  * Same, DEVICE pointers (memory of the handle's device), asynchronous on `stream`

@@ -473,9 +473,11 @@ def test_solve_device_is_ordered_on_the_default_stream():
 
 @pytest.mark.parametrize("B,h,kw", [(4099, 10, dict(vx_cmd=True)), (1023, 10, {}), (5, 10, {}), (2051, 20, dict(vx_cmd=True, per_step_mu=True))])
 def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
-    """`bmpc_solve_batch` / `bmpc_solve_batch_f64` (what REF:487 callers get): pinned staging, up to four chunks on streams of
-    descending priority, a chunk's device-to-host copy and fp64 widening overlapped with the later chunks' solves.  The
-    results must not depend on any of that: both entries against ONE launch of `bmpc_solve_batch_device` over the whole batch,
+    """`bmpc_solve_batch` / `bmpc_solve_batch_f64` (what REF:487 callers get): pinned staging, up to three chunks on streams of
+    descending priority, the kernels storing their results straight into the mapped pinned block, a chunk's unpacking / fp64
+    widening overlapped with the later chunks' solves; and `bmpc_host_io` / `bmpc_solve_batch_io` (round 5): the handle's
+    page-locked I/O block, one copy in, one launch, fp64 results stored by the kernels into the block's host arrays.  The
+    results must not depend on any of that: every entry against ONE launch of `bmpc_solve_batch_device` over the whole batch,
     bit for bit -- controls, states, iteration counts, status, residuals -- for ragged sizes (chunk boundaries off any power
     of two, fewer instances than a chunk), optional inputs, `want_states = False`, caller-owned output arrays, and with a
     dispatch order set (one chunk)."""
@@ -517,6 +519,35 @@ def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
     P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     _lib.check(sol._lib.bmpc_solve_batch(sol._h, B, P(x32[0]), P(x32[1]), P(c8), P(ph), P(xc), P(mu32), P(uf), P(sf), P(itf), None, None, None))
     assert np.array_equal(uf, u1) and np.array_equal(sf, s1) and np.array_equal(itf, info["iters"])
+    # the chunked call spans its kernels with the handle's timing events: first chunk's start to last chunk's end
+    ms_host = sol.last_kernel_ms()
+    sol.solve_device(t["x_fb"], t["foot"], t["contact"], t["phase"], t["x_cmd"], t["mu"])
+    torch.cuda.synchronize()
+    ms_dev = sol.last_kernel_ms()
+    assert 0.5 * ms_dev < ms_host < 3.0 * ms_dev + 0.5, (ms_host, ms_dev)
+    # the handle's page-locked I/O block: results read in place, fp64, the same bits (twice: the block is reused)
+    for _ in range(2):
+        st_i, u_i, i_i = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])
+        assert u_i.dtype == np.float64 and st_i.dtype == np.float64 and u_i.shape == (B, h, 12) and st_i.shape == (B, h, 13)
+        assert np.array_equal(u_i, u) and np.array_equal(st_i, st)
+        assert np.array_equal(i_i["iters"], info["iters"]) and np.array_equal(i_i["status"], info["status"])
+        assert np.array_equal(i_i["nfactor"], info["nfactor"]) and np.array_equal(i_i["residuals"], info["residuals"])
+    st_j, u_j, _ = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
+    assert st_j is None and np.array_equal(u_j, u)
+    # ... and through raw ctypes, the way INTEGRATION.md binds it
+    v = _lib.CHostViews()
+    _lib.check(sol._lib.bmpc_host_io(sol._h, B, int(xc is not None), int(mu32 is not None), 1, C.byref(v)))
+    C.memmove(v.x_fb, x32[0].ctypes.data, x32[0].nbytes); C.memmove(v.foot, x32[1].ctypes.data, x32[1].nbytes)
+    C.memmove(v.contact, c8.ctypes.data, c8.nbytes); C.memmove(v.phase, ph.ctypes.data, ph.nbytes)
+    if xc is not None:
+        C.memmove(v.x_cmd, xc.ctypes.data, xc.nbytes)
+    if mu32 is not None:
+        C.memmove(v.mu, mu32.ctypes.data, mu32.nbytes)
+    _lib.check(sol._lib.bmpc_solve_batch_io(sol._h, B))
+    u_c = np.frombuffer((C.c_char * (B * h * 12 * 8)).from_address(v.controls), np.float64).reshape(B, h, 12)
+    assert np.array_equal(u_c, u)
+    assert sol._lib.bmpc_solve_batch_io(sol._h, B + 1) != 0                 # (laid out for B: anything else is refused)
+    sol._io_key = None                                                      # (the raw call re-laid the block: drop the cached views)
     # a dispatch order indexes the whole batch: one chunk, same results
     order = torch.arange(B - 1, -1, -1, dtype=torch.int32, device=dev)
     sol.set_dispatch_order(order)
