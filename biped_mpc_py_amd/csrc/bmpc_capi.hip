@@ -669,8 +669,10 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
   HIP_TRY(h->dev_in.ensure(in_bytes));
   HIP_TRY(h->pin_out.ensure(out_bytes));
   HIP_TRY(h->dev_out.ensure(out_bytes));
-  // what the handle's own stream holds (a device-pointer solve on BMPC_STREAM_OWN, the warm-start state it writes) comes first
-  HIP_TRY(hipEventRecord(h->cev_own, h->stream));
+  // what the handle's own stream holds (a device-pointer solve on BMPC_STREAM_OWN, the warm-start state it writes) comes first;
+  // an idle stream -- the usual case -- is not made to process a marker the chunk streams would then wait for (tens of us)
+  const bool own_busy = hipStreamQuery(h->stream) != hipSuccess;
+  if (own_busy) HIP_TRY(hipEventRecord(h->cev_own, h->stream));
   struct Chunk { size_t lo, nb, off, o_u, o_s, o_it, o_st, o_nf, o_rs, bytes; } ck[bmpc_handle_s::HOST_CHUNKS];
   size_t off = 0, ioff = 0;
   int issued = 0;                               // chunks whose work is queued (an error below waits for them before returning)
@@ -712,7 +714,7 @@ int solve_host(bmpc_handle h, int B, const float* x_fb, const float* foot, const
     k.bytes = align16(k.o_rs + k.nb * 2 * 4);
     off += k.bytes;
     hipStream_t st = h->cstream[c];
-    HOST_TRY(hipStreamWaitEvent(st, h->cev_own, 0));
+    if (own_busy) HOST_TRY(hipStreamWaitEvent(st, h->cev_own, 0));
     issued = c + 1;
     HOST_TRY(hipMemcpyAsync(din, pin, i_bytes, hipMemcpyHostToDevice, st));
     char* dout = h->dev_out.p + k.off;
@@ -828,7 +830,8 @@ int bmpc_solve_batch_io(bmpc_handle h, int B) {
   int nchunk = whole ? 1 : (int)(n / 512);
   nchunk = nchunk < 1 ? 1 : (nchunk > h->host_chunks ? h->host_chunks : nchunk);
   if (L.states) HIP_TRY(h->io_states.ensure(n * H * 13));
-  HIP_TRY(hipEventRecord(h->cev_own, h->stream));              // what the handle's own stream holds comes first
+  const bool own_busy = hipStreamQuery(h->stream) != hipSuccess;      // what the handle's own stream holds comes first
+  if (own_busy) HIP_TRY(hipEventRecord(h->cev_own, h->stream));
   int issued = 0;
   auto bail = [&](int code) {
     for (int c = 0; c < issued; ++c) (void)hipStreamSynchronize(h->cstream[c]);
@@ -843,7 +846,7 @@ int bmpc_solve_batch_io(bmpc_handle h, int B) {
     const size_t lo = nchunk >= 2 ? (size_t)(n * h->host_cut[c]) : 0;
     const size_t nb = (c == nchunk - 1 ? n : (size_t)(n * h->host_cut[c + 1])) - lo;
     hipStream_t st = h->cstream[c];
-    IO_TRY(hipStreamWaitEvent(st, h->cev_own, 0));
+    if (own_busy) IO_TRY(hipStreamWaitEvent(st, h->cev_own, 0));
     issued = c + 1;
     if (c == 0) {                               // ONE copy in, for the whole batch
       IO_TRY(hipMemcpyAsync(din, h->io_in.p, L.in_bytes, hipMemcpyHostToDevice, st));
