@@ -333,6 +333,11 @@ def run_rank(args):
             else:
                 dist.init_process_group(args.backend, rank=rank, world_size=world)
             dist.barrier()
+        # (rehearsal hook of tests/test_gpu_parity.py: this rank dies the hard way once the group is up -- the launcher has to
+        #  take the others, who then sit in a collective, down with it)
+        if os.environ.get("BMPC_BENCH_KILL_RANK") == str(rank):
+            import signal
+            os.kill(os.getpid(), signal.SIGKILL)
 
     import biped_mpc_py_amd as bm
     from biped_mpc_py_amd import sharding

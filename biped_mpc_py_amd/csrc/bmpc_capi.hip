@@ -45,7 +45,7 @@ bool inv3(const double* a, double* o) {
 }
 
 bool dense_horizon(int h) { return h >= 8 && h <= 20 && h % 2 == 0; }
-bool stage_horizon(int h) { return h >= 8 && h <= 40 && h % 2 == 0; }
+bool stage_horizon(int h) { return h >= 4 && h <= 40; }       // (any parity: steps past the horizon are phantoms of the lane map)
 // the kernel family that solves horizon h when the caller asks for `path`; 0 if there is none
 int resolve_path(int h, int path) {
   if (path == BMPC_PATH_DENSE) return dense_horizon(h) ? BMPC_PATH_DENSE : 0;
@@ -483,6 +483,13 @@ int bmpc_default_params(bmpc_params* p, int h) {
   if (h <= 12) {
     p->adapt_start = 5; p->adapt_every = 5; p->adapt_early = 3; p->adapt_late = 20;
     p->adapt_busy = 10; p->confirm_from = 3; p->kappa_confirm = 400.0;
+  } else if (h < 20) {
+    // h = 14 .. 18 (a factorisation costs 15 iterations): two early re-classifications 10 apart, then 20, confirmation from the
+    // third on.  Model (128 oracle-solved walking instances, h = 16): 57.1 / 4.27 instead of 64.7 / 4.08, worst cost 224 instead
+    // of 270; MI355X, config 3: 2.07 instead of 2.13 ms per 4096.  h = 20 (21 iterations per factorisation) gains nothing from
+    // any of this (6.09 +- 0.03 ms per 8192 over six schedules) and keeps its single rate.
+    p->adapt_start = 10; p->adapt_every = 10; p->adapt_early = 2; p->adapt_late = 20;
+    p->confirm_from = 2; p->kappa_confirm = 400.0;
   }
   p->rescue = BMPC_RESCUE_AUTO;
   p->accel = 1;

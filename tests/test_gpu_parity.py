@@ -660,6 +660,49 @@ def test_bench_bare_n_gpus_reports_the_north_star_partition_and_proves_its_rank_
     assert abs(rf["frac"] - rf["frac_survey_formula"]) < 1e-12 and rf["frac_executed"] < rf["frac"]
 
 
+def test_bench_bare_five_ranks_ragged_shards_and_a_killed_rank():
+    """The driver's N = 8 command rehearsed as far as this box allows: a GPU box admits six processes on its card (the test
+    process is one), so FIVE ranks over gloo on the one GPU (`--backend gloo --share-device`), started bare like the driver
+    does, strong record on a batch of 65539 instances -- five ragged shards (13108 x 4 + 13107) --, one device string per rank,
+    gathered controls bit-identical to rank 0's solve of the whole batch.  (The 8-rank partition itself -- bounds, padding,
+    gather -- is held on the CPU over gloo: tests/test_sharding_gloo.py::test_eight_rank_shard_and_gather.)  Then the same
+    launch with one rank killed (SIGKILL) right after the process group is up: the launcher must come back non-zero in
+    bounded time, print no JSON line and leave no rank behind."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1",
+           "--total", "65539", "--backend", "gloo", "--share-device", "--cpu-sample", "0", "--batch", "1024"]
+    p = subprocess.run(cmd, env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([x for x in p.stdout.decode().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 5 and line["scaling"] == "weak" and line["config"]["total"] == 5 * 1024
+    sr = line["strong"]
+    assert sr["baseline_config"] == 4 and sr["total"] == 65539 and sr["scaling"] == "strong" and sr["value"] > 0
+    assert "bit-identical" in sr["gather_check"] and sr["not_converged_rank0"] == 0 and len(sr["kernel_ms_per_rank"]) == 5
+    rk = line["ranks"]
+    assert rk["world_size_backend"] == 5 and rk["backend"] == "gloo" and len(rk["devices"]) == 5
+    assert all(d.startswith("rank %d:" % i) and "uuid" in d for i, d in enumerate(rk["devices"]))
+    # one rank dies: the launcher takes the rest down
+    t0 = time.time()
+    q = subprocess.run(cmd, env=dict(env, BMPC_BENCH_KILL_RANK="3", BMPC_BENCH_LAUNCH_TIMEOUT="200"), capture_output=True, timeout=400)
+    took = time.time() - t0
+    print("killed rank 3: launcher exit code %d after %.0f s" % (q.returncode, took))
+    assert q.returncode != 0 and took < 300
+    assert not any(ln.startswith("{") for ln in q.stdout.decode("utf-8", "replace").splitlines())
+    import psutil
+    me = os.getpid()
+    ancestors = {a.pid for a in psutil.Process(me).parents()}
+    left = [a for a in psutil.process_iter(["pid", "cmdline", "name"])
+            if a.info["pid"] != me and a.info["pid"] not in ancestors and a.info["cmdline"]
+            and "python" in (a.info["name"] or "") and any(x.endswith("bench.py") for x in a.info["cmdline"][1:3])]
+    assert not left, [(a.info["pid"], a.info["cmdline"]) for a in left]
+
+
 def test_bench_collectives_over_rccl_single_rank_rehearsal():
     """The N > 1 code path of bench.py over RCCL itself, as far as one GPU allows: `--force-dist` initialises the nccl process
     group with ONE rank and runs every collective of the line for real -- the parameter broadcast, the asynchronous
@@ -1224,6 +1267,75 @@ def test_parity_against_the_oracle_at_scale(label, B, h, gait, seed, kw):
         assert e.max() <= util.REL_TOL and e0.max() <= util.REL_TOL
         # regression bounds well inside the tolerance (measured on MI355X: profiles/r04_parity_at_scale.txt)
         assert e.max() <= 1e-5 and e0.max() <= 2e-5, (e.max(), e0.max())
+
+
+# BASELINE's full sizes (configs[3], configs[4]): (label, config number, instances checked against the oracle)
+_FULL_SIZE = [("config4_65536_mixed_h10", 4, 2048), ("config5_65536_mu_h20", 5, 1024)]
+
+
+@pytest.mark.parametrize("label,cfg,nref", _FULL_SIZE, ids=[a[0] for a in _FULL_SIZE])
+def test_full_size_baseline_batches_against_the_oracle(label, cfg, nref):
+    """BASELINE configs 4 and 5 at their FULL sizes -- the very 65536-instance batches `bench.py --config 4 | 5` solves (SURVEY 8(d)
+    generator and seeds), product default path: every instance converges, every constraint of REF:220-271 holds, and the
+    instances that took the most iterations (the hard end of the batch: half of the sample) plus a random half are held to the
+    certified fp64 oracle on the fp32-rounded inputs the GPU saw, on both metrics of SURVEY 8(d) -- all h x 12 controls and the
+    row the reference applies (`u0`, REF:493).  Round 4 measured all 65536 of each by hand (tools/full_size_parity.py,
+    profiles/r04_parity_full_size.txt: config 5's worst u0 3.8e-5, three instances above 2e-5); this puts the full sizes under the
+    driver's eyes.  Bounds: tolerance 1e-4; regression bounds 1e-5 (all controls) and 5e-5 (u0)."""
+    import multiprocessing as mp
+    import os
+    import time
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import synth
+    cf = synth.CONFIGS[cfg]
+    B, h = cf["batch"], cf["h"]
+    assert B == 65536
+    s = synth.synth_batch(B, h, cf["seed"], gait=cf["gait"], **cf["kw"])
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    t0 = time.time()
+    states, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])
+    t_gpu = time.time() - t0
+    sol.close()
+    assert (info["status"] == 0).all(), np.bincount(info["status"])
+    assert np.isfinite(u).all() and np.isfinite(states).all()
+    # every constraint, every instance (REF:220-251; the line-foot rows are held through the oracle sample)
+    mu = s["mu"] if s["mu"] is not None else np.full((B, h, 2), 0.5)
+    f = u.reshape(B, h, 4, 3)
+    tol = 2e-3
+    for j in range(2):
+        c = s["contact"][:, :, j].astype(float)
+        fx, fy, fz = f[:, :, j, 0], f[:, :, j, 1], f[:, :, j, 2]
+        assert (fz >= -tol).all() and (fz <= 500 * c + tol).all()
+        assert (fx >= -tol).all() and (fy >= -tol).all()                              # f_min = 0 on all three axes (REF:46)
+        assert (fx <= mu[:, :, j] * fz + tol).all() and (fy <= mu[:, :, j] * fz + tol).all()
+        assert (np.abs(f[:, :, 2 + j, 0]) <= tol).all()                               # tau_max[0] = 0 (REF:47)
+        assert (np.abs(f[:, :, 2 + j, 1]) <= 67 * c + tol).all() and (np.abs(f[:, :, 2 + j, 2]) <= 33.5 * c + tol).all()
+    # the sample: the hardest half by iteration count (ties: by factorisations), a random half of the rest
+    order = np.lexsort((-info["nfactor"], -info["iters"]))
+    hard = order[:nref // 2]
+    rest = np.random.default_rng(cfg).permutation(order[nref // 2:])[:nref - nref // 2]
+    idx = np.concatenate([hard, rest])
+    r32 = lambda v: v.astype(np.float32).astype(float)
+    args = [(r32(s["x_fb"][i]), r32(s["foot"][i]), s["contact"][i], r32(s["x_cmd"][i]),
+             None if s["mu"] is None else r32(s["mu"][i]), h, s["half"], int(s["phase"][i])) for i in idx]
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:
+        res = pool.map(_oracle_worker, args, chunksize=8)
+    t_orc = time.time() - t0
+    ref = np.stack([r[0] for r in res])
+    ok = np.array([r[1] for r in res])
+    assert ok.mean() > 0.995                                   # (an uncertified reference is no yardstick)
+    e, e0 = util.rel_err(u[idx], ref)[ok], util.u0_err(u[idx], ref)[ok]
+    nh = int(ok[:len(hard)].sum())
+    print("%s: %d instances, all converged; iterations %.1f (max %d), factorisations %.2f (max %d); GPU call %.2f s, oracle %.1f s for %d" % (
+        label, B, info["iters"].mean(), info["iters"].max(), info["nfactor"].mean(), info["nfactor"].max(), t_gpu, t_orc, len(idx)))
+    print("  hardest %d (iterations >= %d): all controls max %.2e, u0 max %.2e | random %d: all controls max %.2e, u0 max %.2e | p99 %.2e / %.2e" % (
+        nh, info["iters"][hard].min(), e[:nh].max(), e0[:nh].max(), len(e) - nh, e[nh:].max(), e0[nh:].max(),
+        np.quantile(e, 0.99), np.quantile(e0, 0.99)))
+    assert e.max() <= util.REL_TOL and e0.max() <= util.REL_TOL
+    assert e.max() <= 1e-5 and e0.max() <= 5e-5, (e.max(), e0.max())
 
 
 _OFF_REFERENCE = {"Q_x10": lambda m: setattr(m, "Q", np.asarray(m.Q, float) * 10.0),

@@ -141,16 +141,17 @@ def test_solver_defaults_follow_the_horizon():
     """`bmpc_default_params(h)`: the re-classification schedule follows the cost of a factorisation relative to an iteration
     (DESIGN.md section 3).  h <= 12 (round 5): 5 apart for the first three (iterations 5, 10, 15), then 20 apart -- 10 after a
     re-classification that still found more than one row in another class --, confirmation (kappa_confirm 400) from the fourth
-    on; h = 16 and 20: every 20 (from iteration 10 resp. 20, rho0 = 0.045 at h = 20), one rate, no confirmation.  1500 instead
+    on; h = 16: iterations 10, 20, then 20 apart, confirmation from the third on; h = 20: every 20 from iteration 20
+    (rho0 = 0.045), one rate, no confirmation.  1500 instead
     of 1000 iterations beyond h = 12 and 60 factorisations allowed everywhere; rho_eq = rho x rho_eq_scale stays 30."""
     import biped_mpc_py_amd as bm
-    want = {10: (5, 5, 3, 20, 10, 1000, 0.03), 16: (20, 10, 0, 0, 0, 1500, 0.03), 20: (20, 20, 0, 0, 0, 1500, 0.045)}
+    want = {10: (5, 5, 3, 20, 10, 1000, 0.03), 16: (10, 10, 2, 20, 0, 1500, 0.03), 20: (20, 20, 0, 0, 0, 1500, 0.045)}
     for h, (every, start, early, late, busy, max_iter, rho) in want.items():
         mpc = bm.MPC()
         mpc.h = h
         cp = bm.pack_params(mpc, bm.Biped())
         assert (cp.adapt_every, cp.adapt_start, cp.adapt_early, cp.adapt_late, cp.adapt_busy, cp.max_iter) == (every, start, early, late, busy, max_iter), h
-        assert (cp.confirm_from, cp.kappa_confirm) == ((3, 400.0) if h == 10 else (0, 0.0)) and cp.adapt_flips == 1, h
+        assert (cp.confirm_from, cp.kappa_confirm) == {10: (3, 400.0), 16: (2, 400.0), 20: (0, 0.0)}[h] and cp.adapt_flips == 1, h
         assert abs(cp.rho - rho) < 1e-12 and abs(cp.rho * cp.rho_eq_scale - 30.0) < 1e-9, h
         assert cp.check_every == 5 and cp.warm_adapt_start == 5 and cp.kappa == 20.0 and cp.max_refactor == 60
     cp = bm.pack_params(bm.MPC(), bm.Biped(), solver_options=dict(adapt_every=15, rho=0.02))      # overrides still apply

@@ -90,3 +90,26 @@ def test_two_rank_shard_and_gather(tmp_path, total):
         got = np.load(tmp_path / f"r{r}.npy")
         assert got.shape == expect.shape
         assert np.array_equal(got, expect)
+
+
+def test_eight_rank_shard_and_gather(tmp_path):
+    """The driver's N = 8 partition (SCALE / MULTICHIP run bare `bench.py --gpus 8`): eight ranks over gloo, ONE seeded batch
+    whose size is not a multiple of eight (65539: three shards of 8193 and five of 8192 -- `shard_bounds` hands the remainder to
+    the first ranks), parameter broadcast from rank 0, disjoint contiguous shards through the real host marshalling, one
+    all_gather of equal-sized padded shards, and on EVERY rank the gathered controls equal the N = 1 result of the whole
+    batch, bit for bit."""
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import sharding
+    world, total = 8, 65539
+    bounds = [sharding.shard_bounds(total, r, world) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == total and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    sizes = [hi - lo for lo, hi in bounds]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == total
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    h = 10
+    host = object.__new__(bm.BatchSolver)
+    host.h = h
+    expect = _solve_shard(host._marshal, h)(**_inputs(total, h))
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npy")
+        assert got.shape == expect.shape and np.array_equal(got, expect)
