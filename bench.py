@@ -166,7 +166,7 @@ def stage_variant(h):
     """(steps a lane owns, waves per instance) of the stage-structured kernel that serves horizon h
     (bmpc_stage.hip: stage_steps_per_lane / stage_waves): one wave up to h = 24, two from h = 26."""
     nw = 1 if h <= 24 else 2
-    return -(-h // (5 * nw)), nw
+    return max(2, -(-h // (5 * nw))), nw
 
 
 def flops_run_stage(h, iters, nfactor):

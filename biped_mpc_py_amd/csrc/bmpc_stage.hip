@@ -1738,7 +1738,10 @@ __global__ void __launch_bounds__(64 * NW) stage_kernel_prof(BMPC_STAGE_ARGS) {
 }
 // steps per lane and waves per instance for horizon h: one wave up to h = 24 (NP = ceil(h / 5)), two from h = 26
 __host__ __device__ constexpr int stage_waves(int h) { return h <= 24 ? 1 : 2; }
-__host__ __device__ constexpr int stage_steps_per_lane(int h) { return (h + 5 * stage_waves(h) - 1) / (5 * stage_waves(h)); }
+__host__ __device__ constexpr int stage_steps_per_lane(int h) {
+  const int np = (h + 5 * stage_waves(h) - 1) / (5 * stage_waves(h));
+  return np < 2 ? 2 : np;                      // (h <= 5: the smallest variant, most of its lane map phantoms)
+}
 #undef BMPC_STAGE_ARGS
 
 }  // namespace bmpc

@@ -132,8 +132,14 @@ def get_reference_foot_trajectory(x_fb, t, foot, mpc, contact, half=None):
     k = phase_index(t, mpc)
     kk = k % hp
     if np.sum(contact[0, :]) == 1:
-        return np.concatenate(
+        out = np.concatenate(
             (np.tile(foot, (1, hp - kk)), np.tile(foot_1, (1, hp)), np.tile(foot_2, (1, kk))), axis=1)
+        if half is not None and out.shape[1] != h:
+            # (extension: a horizon that is not two half periods -- odd h, or a half period of the caller's choice -- keeps the
+            #  second touch-down point to the end of the horizon, resp. stops at the horizon: what the kernels' column rule
+            #  j < half - kk / j < 2 half - kk / else gives.  With half = h / 2 nothing changes.)
+            out = np.concatenate((out, np.tile(foot_2, (1, max(h - out.shape[1], 0)))), axis=1)[:, :h]
+        return out
     return np.tile(foot, (1, h))
 
 

@@ -9,6 +9,8 @@ h-generic code) and pinned by the KKT certificate alone, exactly like cfg3_trot_
   cfg_h32, cfg_h40      64 instances each: walking (half = h/2, random phase), commanded v_x, per-step per-foot mu
                         -- the long-horizon cases of SURVEY 8(f) row 4 (stage-structured kernels)
   cfg_hgen              4 instances for every other even horizon in [8, 38]: the horizon as a launch parameter
+  cfg_hodd              4 instances for h = 4, 5, 7, 9, 15, 21, 33: short and odd horizons (REF:24 takes any int; half = h // 2,
+                        the second touch-down point kept to the end of the horizon -- oracle.get_reference_foot_trajectory)
 
 Usage:  python oracle/gen_golden_ext.py [names...]        (writes tests/golden/*.npz; minutes on 8 cores)
 """
@@ -62,7 +64,8 @@ def make_args(rng, h, n, use_mu=True):
 def main(names):
     os.makedirs(OUT, exist_ok=True)
     jobs = {"cfg_h32": [(32, 64, 32)], "cfg_h40": [(40, 64, 40)],
-            "cfg_hgen": [(h, 4, 500 + h) for h in range(8, 40, 2) if h not in (10, 16, 20, 32)]}
+            "cfg_hgen": [(h, 4, 500 + h) for h in range(8, 40, 2) if h not in (10, 16, 20, 32)],
+            "cfg_hodd": [(h, 4, 600 + h) for h in (4, 5, 7, 9, 15, 21, 33)]}
     with Pool(min(8, os.cpu_count() or 1)) as pool:
         for name in names or list(jobs):
             t0 = time.time()
@@ -70,7 +73,7 @@ def main(names):
             for h, n, seed in jobs[name]:
                 args += make_args(np.random.default_rng(seed), h, n)
             cases = pool.map(_case, args, chunksize=1)
-            if name == "cfg_hgen":             # ragged horizons: one record per horizon inside one file
+            if name in ("cfg_hgen", "cfg_hodd"):   # ragged horizons: one record per horizon inside one file
                 rec = {}
                 for h, n, _ in jobs[name]:
                     cs = [c for c in cases if int(c["hor"]) == h]

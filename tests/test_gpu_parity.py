@@ -974,20 +974,40 @@ def test_rollout_longest_first_dispatch_same_results_less_time():
 # ------------------------------------------------------------------------------------------------------------------
 
 
-def _hgen(h):
-    d = util.load("cfg_hgen")
+def _hgen(h, name="cfg_hgen"):
+    d = util.load(name)
     return {k: d["h%d_%s" % (h, k)] for k in ("x_fb", "t", "foot", "contact", "x_cmd", "mu_steps", "controls", "states", "half")}
 
 
-def test_every_even_horizon_is_supported():
-    """REF:24: `h` is a plain field of MPC.  Every even horizon in [8, 40] has a kernel; the dense family ends at 20."""
+def test_every_horizon_is_supported():
+    """REF:24: `h` is a plain field of MPC.  Every horizon in [4, 40] has a kernel (round 5: odd and short ones on the stage
+    family, whose lane map takes any number of steps -- the rest are phantoms); the dense family has the even ones in [8, 20]."""
     from biped_mpc_py_amd import _lib
     lib = _lib.load()
-    for h in range(2, 48):
-        want = 1 if (8 <= h <= 40 and h % 2 == 0) else 0
+    for h in range(1, 48):
+        want = 1 if 4 <= h <= 40 else 0
         assert lib.bmpc_supported_horizon(h) == want, h
         assert lib.bmpc_supported_horizon_path(h, PATH_STAGE) == want, h
-        assert lib.bmpc_supported_horizon_path(h, PATH_DENSE) == (want if h <= 20 else 0), h
+        assert lib.bmpc_supported_horizon_path(h, PATH_DENSE) == (1 if (8 <= h <= 20 and h % 2 == 0) else 0), h
+
+
+@pytest.mark.parametrize("h", [4, 5, 7, 9, 15, 21, 33])
+def test_odd_and_short_horizons(h):
+    """REF:24 takes any int.  Odd and short horizons (oracle-solved extension fixtures, 4 instances each: walking with half
+    period h // 2 -- the second touch-down point kept to the end of the horizon --, commanded v_x, per-step friction) run on the
+    stage-structured family: its lane map takes any number of steps (h = 4, 5: most of the smallest variant's slots are
+    phantoms; h = 21: five steps per lane; h = 33: two waves).  AUTO resolves to it."""
+    g = _hgen(h, "cfg_hodd")
+    for path in (PATH_AUTO, PATH_STAGE):
+        solver, mpc = _solver(h, int(g["half"][0]), path=path)
+        assert solver._lib.bmpc_solver_path(solver._h) == PATH_STAGE
+        states, controls, info = solver.solve(g["x_fb"], g["foot"], g["contact"], util.phases(g["t"], mpc.dt, h),
+                                              x_cmd=g["x_cmd"], mu=g["mu_steps"])
+        e, es = util.rel_err(controls, g["controls"]), util.rel_err(states, g["states"])
+        print("h=%d path %d: err %.2e / %.2e iters %s" % (h, path, e.max(), es.max(), info["iters"]))
+        assert (info["status"] == 0).all()
+        assert e.max() <= util.REL_TOL and es.max() <= util.REL_TOL
+        solver.close()
 
 
 @pytest.mark.parametrize("name", ["cfg2_standing_h10", "cfg4_walking_h10", "edge_cases_h10", "cfg3_trot_h16", "cfg5_mu_h20",
