@@ -519,7 +519,8 @@ solve_body(const DevParams& P, const int B,
   sync_workgroup();
 #endif
   long long t_start = 0, t_setup = 0, t_blocks = 0, t_sweep = 0, t_mark = 0;
-  long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+  long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0, t_red = 0, t_reb = 0;   // (t_red, t_reb: inside t_ph[6], the iteration's tail)
+  int n_reb = 0;
 #define BMPC_STAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
   if constexpr (PROF) t_start = clock64();
   const int l = threadIdx.x;
@@ -1692,6 +1693,8 @@ solve_body(const DevParams& P, const int B,
     if (check_now || adapt_do) {
       float v5[8] = {rp, rs, nz, nx, chg, slw, aa1, aa2};
       float u0v[3] = {0.f, 0.f, 0.f};           // step 0: residuals, norm, pull of its inactive rows
+      long long t_r0 = 0;
+      if constexpr (PROF) t_r0 = clock64();
       if constexpr (AA) {
         float v12[12] = {rp, rs, nz, nx, chg, slw, r0, nx0, slw0, aa1, aa2, nflip};
         block_max_sum<NT, 9, 3, 3>(v12, sm.red[n_red & 1]);
@@ -1707,6 +1710,7 @@ solve_body(const DevParams& P, const int B,
         for (int q = 0; q < 6; ++q) v5[q] = v6[q];
       }
       ++n_red;
+      if constexpr (PROF) t_red += clock64() - t_r0;
       if (check_now) {
         res_p = v5[0];
         res_s = v5[1];
@@ -1742,8 +1746,11 @@ solve_body(const DevParams& P, const int B,
         next_check += far ? 2 * check_every : check_every;
         // (on the way out only the net wrench is needed, for the states: the iterate is what it is)
         const bool leaving = bad || done || it == P.max_iter;
+        long long t_b0 = 0;
+        if constexpr (PROF) t_b0 = clock64();
         if (leaving) refresh(false);
-        else if (rebuild) { refresh(true); last_exact = it; }
+        else if (rebuild) { refresh(true); last_exact = it; ++n_reb; }
+        if constexpr (PROF) { if (leaving || rebuild) t_reb += clock64() - t_b0; }
         if (bad) { status = 2; break; }
         if (done) { status = 0; break; }
       }
@@ -1870,6 +1877,7 @@ solve_body(const DevParams& P, const int B,
     pr[0] = t_setup; pr[1] = t_blocks; pr[2] = t_sweep; pr[3] = clock64() - t_start; pr[4] = it; pr[5] = nfac;
 #pragma unroll
     for (int k = 0; k < 7; ++k) pr[8 + k] = t_ph[k];
+    pr[6] = t_red; pr[7] = t_reb; pr[15] = (long long)n_red * 1000 + n_reb;
   }
   if (l == 0) {
     if (iters_out) iters_out[inst] = it;

@@ -31,3 +31,6 @@ print('cycles mean: setup %.0f blocks %.0f sweeps %.0f total %.0f | iters %.1f n
 it=pr[:,3]-pr[:,0]-pr[:,1]-pr[:,2]
 print('iteration cycles per iter %.0f ; blocks per factor %.0f ; sweep per factor %.0f'%((it/pr[:,4]).mean(),(pr[:,1]/pr[:,5]).mean(),(pr[:,2]/pr[:,5]).mean()))
 print('iteration phases, cycles per iteration: ' + ' '.join('%s %.0f'%(n,v) for n,v in zip(['P0','P1','P2','P3','P4','P5','tail'], (pr[:,8:15]/pr[:,4:5]).mean(0))))
+nred=np.floor(pr[:,15]/1000); nreb=pr[:,15]-1000*nred
+print('tail per solve: %.0f cycles = reductions %.0f (%.1f of them, %.0f each) + rebuilds / last refresh %.0f (%.2f rebuilds) + rest %.0f'%(
+    pr[:,14].mean(), pr[:,6].mean(), nred.mean(), (pr[:,6]/np.maximum(nred,1)).mean(), pr[:,7].mean(), nreb.mean(), (pr[:,14]-pr[:,6]-pr[:,7]).mean()))
