@@ -957,6 +957,9 @@ stage_body(const DevParams& P, const int B,
   while (next_adapt < 1) next_adapt += P.adapt_every;
   int n_adapt = 0;                             // re-classifications taken (the two-rate schedule: DevParams::adapt_early)
   int prev_act = 0;                            // classes of this lane's rows at the previous re-classification (bits 2 s: box row, 2 s + 1: general row of step slot s)
+  // (like the secant step, not with five steps per lane -- h = 21 .. 24: no registers; those horizons re-classify adapt_late apart
+  //  after the early ones whatever the rows did, and confirm nothing.  Their defaults use neither.)
+  constexpr bool FLIPS = NP <= 4;
   float res_p = 0.f, res_s = 0.f;
   const RT idt_r = (RT)1 / dt, dtm = dt / (RT)P.m;
 
@@ -1406,14 +1409,13 @@ stage_body(const DevParams& P, const int B,
       const bool actb = (zbv <= (RT)lb[s] || zbv >= (RT)ub[s]) && ybv != (RT)0;
       const bool actg = (zgv >= (RT)0) && ygv != (RT)0;
       act2 = (actb ? 1 : 0) | (actg ? 2 : 0);
-      const bool confirm = scheduled && P.kappa_confirm > 0.f && n_adapt >= P.confirm_from && n_adapt > 0 && nfac <= 10;   // (n_adapt: before this one)
+      const bool confirm = FLIPS && scheduled && P.kappa_confirm > 0.f && n_adapt >= P.confirm_from && n_adapt > 0 && nfac <= 10;   // (n_adapt: before this one)
       const int same = confirm ? ~(act2 ^ (prev_act >> (2 * s))) : 0;
       const float kapb = (same & 1) ? P.kappa_confirm : kap, kapg = (same & 2) ? P.kappa_confirm : kap;
       const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
       nb = eqb[s] ? P.rho_eq : (actb ? fminf(rvb[s] * kapb, hib) : fmaxf(rvb[s] / kapb, P.rho_lo));
       ng = actg ? fminf(rvg[s] * kapg, hig) : fmaxf(rvg[s] / kapg, P.rho_lo);
     };
-    int act_now = 0;                          // the classes this re-classification finds (packed like prev_act)
     float nflip = 0.f;                        // this lane's rows in another class than at the previous re-classification
     // --- P5: x~ = x - d, z~ = A x~ (carried), relaxation, projection, dual update, tracking error
     float rp = 0.f, rs = 0.f, nz = 0.f, nx = 0.f, slw = 0.f;
@@ -1518,9 +1520,10 @@ stage_body(const DevParams& P, const int B,
             int a2;
             reclassify_v(s, znb, ybn, zng, ygn, nb, ng, a2, true);
             chg_t = ((nb != rvb[s]) | (ng != rvg[s])) ? 1.f : chg_t;
-            act_now |= a2 << (2 * s);
-            const int fl = a2 ^ ((prev_act >> (2 * s)) & 3);
-            nflip += (lane_real && n_adapt > 0) ? (float)((fl & 1) + (fl >> 1)) : 0.f;
+            if constexpr (FLIPS) {
+              const int fl = a2 ^ ((prev_act >> (2 * s)) & 3);
+              nflip += (lane_real && n_adapt > 0) ? (float)((fl & 1) + (fl >> 1)) : 0.f;
+            }
           }
         }
       } else {
@@ -1577,9 +1580,10 @@ stage_body(const DevParams& P, const int B,
           int a2;
           reclassify(s, nb, ng, a2, true);
           chg = (sreal[s] && ((nb != rvb[s]) | (ng != rvg[s]))) ? 1.f : chg;
-          act_now |= a2 << (2 * s);
-          const int fl = a2 ^ ((prev_act >> (2 * s)) & 3);
-          nflip += (sreal[s] && lane_real && n_adapt > 0) ? (float)((fl & 1) + (fl >> 1)) : 0.f;
+          if constexpr (FLIPS) {
+            const int fl = a2 ^ ((prev_act >> (2 * s)) & 3);
+            nflip += (sreal[s] && lane_real && n_adapt > 0) ? (float)((fl & 1) + (fl >> 1)) : 0.f;
+          }
         }
       }
       // (see bmpc_kernels.hip: the third stopping test -- the pull rho |z~ - z| of the inactive rows against the softest
@@ -1665,7 +1669,18 @@ stage_body(const DevParams& P, const int B,
       }
     }
     if (adapt_now) {                          // the schedule: bmpc_kernels.hip
-      if (adapt_do) prev_act = act_now;
+      if constexpr (FLIPS) {
+        if (adapt_do) {                         // the classes as the instance leaves this re-classification (from the committed state:
+          int an = 0;                           //  nothing is carried across the reduction for it)
+#pragma unroll
+          for (int s = 0; s < NP; ++s) {
+            const bool actb = (zb[s] <= (RT)lb[s] || zb[s] >= (RT)ub[s]) && yb[s] != (RT)0;
+            const bool actg = (zg[s] >= (RT)0) && yg[s] != (RT)0;
+            an |= ((actb ? 1 : 0) | (actg ? 2 : 0)) << (2 * s);
+          }
+          prev_act = an;
+        }
+      }
       ++n_adapt;
       int period = P.adapt_every;
       if (P.adapt_late > 0 && n_adapt >= P.adapt_early)
