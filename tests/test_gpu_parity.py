@@ -552,8 +552,10 @@ def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
     order = torch.arange(B - 1, -1, -1, dtype=torch.int32, device=dev)
     sol.set_dispatch_order(order)
     _, u3, i3 = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"], want_states=False)
-    sol.set_dispatch_order(None)
+    st4, u4, i4 = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], mu=s["mu"])   # (one chunk: states straight
+    sol.set_dispatch_order(None)                                                                                     #  from the kernel too)
     assert np.array_equal(u3, u) and np.array_equal(i3["iters"], info["iters"])
+    assert np.array_equal(u4, u) and np.array_equal(st4, st) and np.array_equal(i4["iters"], info["iters"])
     sol.close()
 
 
