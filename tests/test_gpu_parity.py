@@ -559,6 +559,31 @@ def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
     sol.close()
 
 
+def test_io_block_edges():
+    """`bmpc_host_io` / `bmpc_solve_batch_io` at the edges: one instance (no chunking), a layout larger than `max_batch` refused,
+    a solve before any layout refused, a re-layout for another batch size (the views move: the wrapper re-reads them), and results
+    equal to `solve` every time."""
+    import ctypes as C
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import _lib
+    sol = bm.BatchSolver(max_batch=600)
+    assert sol._lib.bmpc_solve_batch_io(sol._h, 1) != 0                    # no layout yet
+    v = _lib.CHostViews()
+    assert sol._lib.bmpc_host_io(sol._h, 601, 0, 0, 1, C.byref(v)) != 0    # beyond max_batch
+    assert sol._lib.bmpc_host_io(sol._h, 0, 0, 0, 1, C.byref(v)) != 0
+    for B in (1, 600, 37):
+        s = util.synth_batch(B, 10, 4100 + B, gait="mixed", vx_cmd=True)
+        st, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+        st_i, u_i, i_i = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+        assert u_i.shape == (B, 10, 12) and np.array_equal(u_i, u) and np.array_equal(st_i, st)
+        assert np.array_equal(i_i["iters"], info["iters"]) and (i_i["status"] == 0).all()
+    # the reference's own single step through the in-place path (REF:475-487 inputs of the standing known answer)
+    k = util.load("known_standing")
+    st1, u1, _ = sol.solve_inplace(k["x_fb"][None], k["foot"][None], k["contact"][None], np.array([util.phases(np.array([float(k["t"])]), 0.04, 10)[0]]))
+    assert util.rel_err(u1, k["controls"][None]).max() <= util.REL_TOL
+    sol.close()
+
+
 def test_dropin_reuses_one_handle_and_reports_status():
     """The drop-in wrappers keep ONE handle per (horizon, device) however often the command changes (ADVICE r1:
     one handle per distinct parameter block leaked streams and buffers), answers follow the changed
