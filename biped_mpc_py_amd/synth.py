@@ -30,7 +30,7 @@ def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_m
         phase = np.zeros(B, np.int32)
         contact = np.ones((B, h, 2), np.uint8)
     else:
-        leg0 = (np.arange(4 * half) // half) % 2 == 0
+        leg0 = (np.arange(max(4 * half, 2 * h)) // half) % 2 == 0        # (periodic; 2 h rows serve every phase, odd h included)
         table = np.stack([leg0, ~leg0], 1).astype(np.uint8)
         phase = rng.integers(0, h, B).astype(np.int32)
         contact = np.stack([table[k:k + h] for k in phase])
