@@ -1443,6 +1443,17 @@ def test_dense_family_away_from_the_reference_weights_and_the_rescue_pass(h):
         assert int((i1["status"] != 0).sum()) == 0
         keep = np.setdiff1d(np.arange(B), lost)
         assert np.array_equal(u1[keep], u0[keep]) and np.array_equal(i1["iters"][keep], i0["iters"][keep])
+        # ... and through the handle's page-locked I/O block (round 5): the rescue launch stores its fp64 results into the same host
+        # arrays -- straight from its epilogue (controls) and by the chunks' copies (states)
+        mpc = bm.MPC()
+        mpc.h = h
+        mod(mpc)
+        sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=dict(rescue=RESCUE_ON, **bad))
+        st_a, u_a, i_a = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], mu=s["mu"])
+        st_b, u_b, i_b = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], mu=s["mu"])
+        assert np.array_equal(u_a, u1) and np.array_equal(u_b, u_a) and np.array_equal(st_b, st_a)
+        assert np.array_equal(i_b["iters"], i_a["iters"]) and int((i_b["status"] != 0).sum()) == 0
+        sol.close()
         ref = _oracle_controls(s, lost[:4], h, mod, None)
         rel = util.rel_err(u1[lost[:4]], ref)
         print("rescued instances: err max %.2e" % rel.max())
