@@ -204,6 +204,36 @@ struct PinnedBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
 };
 
+// The same for memory the CALLER holds pointers into (the I/O block of bmpc_host_io): a block that has to grow is not freed but
+// retired until the handle goes -- a view of the old layout that a caller still holds must not dangle --, and it grows by half at
+// least, so that what is retired stays below twice what is in use.
+struct RetiringPinnedBuf {
+  char* p = nullptr;
+  size_t n = 0;
+  static constexpr int MAX_RETIRED = 64;
+  char* retired[MAX_RETIRED] = {};
+  int n_retired = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= n) return hipSuccess;
+    size_t cap = n + n / 2;
+    if (cap < bytes) cap = bytes;
+    char* q = nullptr;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&q), cap, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) return e;
+    if (p) {
+      if (n_retired < MAX_RETIRED) retired[n_retired++] = p;
+      else (void)hipHostFree(p);              // (64 growths by half: a block 10^11 times the first one -- not reached)
+    }
+    p = q; n = cap;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    for (int i = 0; i < n_retired; ++i) (void)hipHostFree(retired[i]);
+    p = nullptr; n = 0; n_retired = 0;
+  }
+};
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -247,7 +277,7 @@ struct bmpc_handle_s {
   bool host_timing = false;
   // the handle's I/O block (bmpc_host_io / bmpc_solve_batch_io): page-locked host memory, mapped into the device's address
   // space -- the caller writes its inputs there, the kernels store the fp64 results there
-  PinnedBuf io_in, io_out;
+  RetiringPinnedBuf io_in, io_out;
   DevBuf<char> io_dev;
   DevBuf<double> io_states;         // fp64 states of a batch in HBM, on their way to the I/O block by copy engine
   hipEvent_t cev_in = nullptr;      // the I/O block's inputs have arrived

@@ -238,8 +238,9 @@ int bmpc_solve_batch_f64(bmpc_handle h, int B,
  * chunk's states go the way of the controls) -- on MI355X a kernel's own stores into host memory sustain ~8.6 GB/s, the copy
  * engine ~50 GB/s, and a 4096-instance batch returns 8.2 MB in 0.8 ms.
  *   bmpc_host_io(h, B, with_x_cmd, with_mu, with_states, &views)   lays the block out for batches of exactly B instances and
- *       returns the array pointers (layouts as in bmpc_solve_batch; x_cmd / mu / states NULL unless asked for).  The views stay
- *       valid until the next bmpc_host_io of this handle or bmpc_destroy.
+ *       returns the array pointers (layouts as in bmpc_solve_batch; x_cmd / mu / states NULL unless asked for).  The views hold
+ *       this layout until the next bmpc_host_io of the handle (another layout re-uses or outgrows the block; the memory behind
+ *       an old view is not freed before bmpc_destroy, so a stale view reads stale data, never unmapped memory).
  *   bmpc_solve_batch_io(h, B)   solves what the input views hold; synchronous: on return the output views hold the results.
  * Ordered after whatever the handle's own stream held when the call began (BMPC_STREAM_OWN launches).  Warm start, dispatch
  * order and the rescue pass apply as for bmpc_solve_batch_device (with warm start or a dispatch order: one chunk).
