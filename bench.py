@@ -56,8 +56,8 @@ PEAK_FP64_TFLOPS = 78.6           # MI355X fp64 vector peak (AMD spec sheet: hal
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # (0.08 s of timed region at the default configuration: box-to-box and
+    ap.add_argument("--warmup", type=int, default=5)       #  run-to-run differences of a 17 ms region were +-2 %)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5, 6, 7),
                     help="BASELINE.json config number (1-based); 6 / 7: the long-horizon extensions h = 32 / 40")
     ap.add_argument("--path", choices=("auto", "dense", "stage", "best"), default=None,
