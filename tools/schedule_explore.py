@@ -7,7 +7,8 @@ Two modes over the same list of schedules (start, early period, early count, lat
                                                       oracle-solved tuning sets; cost = iterations + c_h x factorisations, c_h the
                                                       measured cost of a factorisation in iterations (10.1 / 15.6 / 21.5 at h = 10 / 16 / 20)
     python tools/schedule_explore.py gpu [configs]    GPU: the library on the same sets (worst error against the oracle, lost
-                                                      instances, counts) and the kernel time of the BASELINE batches (min of 4 launches)
+                                                      instances, counts) and the BASELINE batches' counts (for kernel TIMES use
+                                                      tools/option_timing.py: device-resident, interleaved, several batches)
 
 Round-5 finding (model, then confirmed on MI355X): the active set is found early -- of 240 rows 45 change class between
 iterations 10 and 20, < 1 after iteration 40 -- so re-classifying 5 apart at first and 20 apart later takes fewer iterations AND
@@ -23,11 +24,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FAC_COST = {10: 10.1, 16: 15.6, 20: 21.5}
-# (start, every, early, late); early = 0: one rate (the schedule up to round 4)
+# (start, every, early, late[, busy, flips, kappa_confirm, confirm_from]); early = 0: one rate (the schedule up to round 4);
+# busy = 0: adapt_late always; kappa_confirm = 0: no confirmation.  First entry of a horizon: the round-4 default; second: round 5's.
 SCHEDULES = {
-    10: [(10, 10, 0, 0), (5, 5, 3, 20), (5, 5, 4, 20), (5, 5, 3, 15), (5, 5, 2, 15), (5, 10, 0, 0), (6, 6, 3, 20), (4, 4, 4, 20), (5, 5, 4, 25), (5, 5, 3, 25)],
-    16: [(10, 20, 0, 0), (10, 10, 3, 20), (10, 10, 2, 20), (10, 5, 3, 20), (8, 8, 2, 20), (10, 10, 3, 30)],
-    20: [(20, 20, 0, 0), (10, 10, 3, 20), (10, 10, 2, 30), (20, 10, 2, 20), (10, 10, 4, 30), (15, 15, 2, 30)],
+    10: [(10, 10, 0, 0), (5, 5, 3, 20, 10, 1, 400.0, 3), (5, 5, 3, 20), (5, 5, 3, 20, 10, 1), (5, 5, 3, 20, 0, 1, 400.0, 3), (5, 5, 4, 20), (5, 5, 3, 15),
+         (5, 5, 2, 15), (5, 10, 0, 0), (6, 6, 3, 20), (4, 4, 4, 20), (5, 5, 3, 20, 10, 1, 400.0, 0), (5, 5, 3, 20, 5, 0, 400.0, 3)],
+    16: [(10, 20, 0, 0), (10, 10, 2, 20, 0, 1, 400.0, 2), (10, 10, 3, 20), (10, 10, 2, 20), (10, 5, 3, 20), (8, 8, 2, 20), (10, 10, 3, 30, 15, 1, 400.0, 3)],
+    20: [(20, 20, 0, 0), (10, 10, 3, 20), (10, 10, 2, 30), (20, 10, 2, 20, 0, 1, 400.0, 2), (10, 10, 4, 30), (15, 15, 3, 30, 0, 1, 400.0, 3)],
 }
 RHO = {10: 0.03, 16: 0.03, 20: 0.045}
 
@@ -48,7 +51,8 @@ def _model_job(a):
     name, z, sched = a
     h = int(z["h"])
     P = wm.Params(h=h, half=int(z["half"]))
-    P.adapt_start, P.adapt_every, P.adapt_early, P.adapt_late = sched
+    sc = tuple(sched) + (0, 1, 0.0, 0)[len(sched) - 4:]
+    P.adapt_start, P.adapt_every, P.adapt_early, P.adapt_late, P.adapt_busy, P.adapt_flips, P.kappa_confirm, P.confirm_from = sc
     P.rho = RHO[h]
     P.rho_eq_scale = 30.0 / P.rho
     P.slow_guard, P.max_iter = 1e-6, 400
@@ -75,7 +79,7 @@ def run_model(which):
         print("set %s (h = %d, %d instances): start/every/early/late -> iterations, factorisations, cost mean / p95 / max, lost, worst error" % (n, int(sets[n]["h"]), len(sets[n]["ref"])))
         base = rows[0][2][2]
         for _, s, r in rows:
-            print("  %-16s it %5.1f nf %4.2f cost %6.1f (%+5.1f %%) p95 %6.1f max %6.1f lost %d err %.1e" % ("%d/%d/%d/%d" % s, r[0], r[1], r[2], 100 * (r[2] / base - 1), r[3], r[4], r[5], r[6]))
+            print("  %-28s it %5.1f nf %4.2f cost %6.1f (%+5.1f %%) p95 %6.1f max %6.1f lost %d err %.1e" % ("/".join("%g" % v for v in s), r[0], r[1], r[2], 100 * (r[2] / base - 1), r[3], r[4], r[5], r[6]))
 
 
 def run_gpu(configs):
@@ -91,7 +95,8 @@ def run_gpu(configs):
         mpc.h = h
         print("config %d (h = %d, B = %d): start/every/early/late -> kernel ms (min of 4), iterations / factorisations, lost | tuning sets of this horizon: worst error, lost, counts" % (c, h, B), flush=True)
         for sched in SCHEDULES[h]:
-            opts = dict(zip(("adapt_start", "adapt_every", "adapt_early", "adapt_late"), sched))
+            sc = tuple(sched) + (0, 1, 0.0, 0)[len(sched) - 4:]
+            opts = dict(zip(("adapt_start", "adapt_every", "adapt_early", "adapt_late", "adapt_busy", "adapt_flips", "kappa_confirm", "confirm_from"), sc))
             sv = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B, solver_options=opts)
             ms = []
             for _ in range(5):
@@ -109,7 +114,7 @@ def run_gpu(configs):
                 ref = z["ref"]
                 rel = np.abs(u2 - ref).reshape(len(u2), -1).max(1) / np.maximum(1.0, np.abs(ref).reshape(len(u2), -1).max(1))
                 cols.append("%s %.1e lost %d %5.1f/%4.2f" % (n, rel.max(), int((i2["status"] != 0).sum()), i2["iters"].mean(), i2["nfactor"].mean()))
-            print("  %-16s %8.4f ms  %5.1f / %4.2f  lost %d  max it %d | %s" % ("%d/%d/%d/%d" % sched, min(ms[1:]), info["iters"].mean(), info["nfactor"].mean(),
+            print("  %-28s %8.4f ms  %5.1f / %4.2f  lost %d  max it %d | %s" % ("/".join("%g" % v for v in sched), min(ms[1:]), info["iters"].mean(), info["nfactor"].mean(),
                                                                           int((info["status"] != 0).sum()), int(info["iters"].max()), " | ".join(cols)), flush=True)
 
 
