@@ -45,7 +45,7 @@ bool inv3(const double* a, double* o) {
 }
 
 bool dense_horizon(int h) { return h >= 8 && h <= 20 && h % 2 == 0; }
-bool stage_horizon(int h) { return h >= 4 && h <= 40; }       // (any parity: steps past the horizon are phantoms of the lane map)
+bool stage_horizon(int h) { return h >= 1 && h <= 40; }       // (any parity, from ONE step: steps past the horizon are phantoms of the lane map)
 // the kernel family that solves horizon h when the caller asks for `path`; 0 if there is none
 int resolve_path(int h, int path) {
   if (path == BMPC_PATH_DENSE) return dense_horizon(h) ? BMPC_PATH_DENSE : 0;

@@ -166,7 +166,7 @@ typedef struct bmpc_handle_s* bmpc_handle;
 /* Library / ABI identification. */
 int bmpc_abi_version(void);
 const char* bmpc_last_error(void);
-/* 1 if a kernel is built for this horizon, else 0: every h in [4, 40] (REF:24: the horizon is a plain field of MPC; odd and
+/* 1 if a kernel is built for this horizon, else 0: every h in [1, 40] (REF:24: the horizon is a plain field of MPC; odd and
  * short horizons run on the stage-structured family).
  * bmpc_supported_horizon_path(h, path) asks for one kernel family (dense: even h in [8, 20]). */
 int bmpc_supported_horizon(int h);

@@ -94,7 +94,8 @@ def get_contact_sequence(t, mpc, half=None):
         half_, nrow = 5, 10
     else:
         half_, nrow = int(half), mpc.h
-    leg0 = (np.arange(4 * half_) // half_) % 2 == 0
+    # (periodic: 4 half rows are two periods, which serve every phase while h <= 2 half; shorter periods get as many rows as k + h needs)
+    leg0 = (np.arange(max(4 * half_, 2 * nrow)) // half_) % 2 == 0
     table = np.stack([leg0, ~leg0], axis=1).astype(int)
     k = phase_index(t, mpc)
     return table[k:k + nrow, :]

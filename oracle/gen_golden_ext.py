@@ -9,8 +9,9 @@ h-generic code) and pinned by the KKT certificate alone, exactly like cfg3_trot_
   cfg_h32, cfg_h40      64 instances each: walking (half = h/2, random phase), commanded v_x, per-step per-foot mu
                         -- the long-horizon cases of SURVEY 8(f) row 4 (stage-structured kernels)
   cfg_hgen              4 instances for every other even horizon in [8, 38]: the horizon as a launch parameter
-  cfg_hodd              4 instances for h = 4, 5, 7, 9, 15, 21, 33: short and odd horizons (REF:24 takes any int; half = h // 2,
-                        the second touch-down point kept to the end of the horizon -- oracle.get_reference_foot_trajectory)
+  cfg_hodd              4 instances for h = 1, 2, 3, 4, 5, 7, 9, 15, 21, 33: short and odd horizons (REF:24 takes any int;
+                        half = max(1, h // 2), the second touch-down point kept to the end of the horizon --
+                        oracle.get_reference_foot_trajectory)
 
 Usage:  python oracle/gen_golden_ext.py [names...]        (writes tests/golden/*.npz; minutes on 8 cores)
 """
@@ -55,9 +56,10 @@ def make_args(rng, h, n, use_mu=True):
         t = k * mp.dt + 0.5 * mp.dt
         x_cmd = np.array(mp.x_cmd, float)
         x_cmd[9] = float(np.float32(rng.uniform(-0.5, 0.5)))
-        contact = orc.get_contact_sequence(t, mp, half=h // 2)
+        half = max(1, h // 2)
+        contact = orc.get_contact_sequence(t, mp, half=half)
         mu = rng.uniform(0.3, 0.9, (h, 2)).astype(np.float32).astype(float) if use_mu else None
-        out.append((x_fb, t, foot, contact, h, h // 2, x_cmd, mu))
+        out.append((x_fb, t, foot, contact, h, half, x_cmd, mu))
     return out
 
 
@@ -65,7 +67,7 @@ def main(names):
     os.makedirs(OUT, exist_ok=True)
     jobs = {"cfg_h32": [(32, 64, 32)], "cfg_h40": [(40, 64, 40)],
             "cfg_hgen": [(h, 4, 500 + h) for h in range(8, 40, 2) if h not in (10, 16, 20, 32)],
-            "cfg_hodd": [(h, 4, 600 + h) for h in (4, 5, 7, 9, 15, 21, 33)]}
+            "cfg_hodd": [(h, 4, 600 + h) for h in (1, 2, 3, 4, 5, 7, 9, 15, 21, 33)]}
     with Pool(min(8, os.cpu_count() or 1)) as pool:
         for name in names or list(jobs):
             t0 = time.time()

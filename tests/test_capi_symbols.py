@@ -42,7 +42,7 @@ def test_default_params_are_reference_defaults(lib):
     assert list(cp.R) == [1e-4] * 12
     assert list(cp.x_cmd) == [0, 0, 0, 0, 0, 0.55, 0, 0, 0, 0, 0, 0]
     assert list(cp.tau_max) == [0, 67, 33.5] and list(cp.tau_min) == [0, -67, -33.5]
-    assert [lib.bmpc_supported_horizon(h) for h in (10, 16, 20, 11, 4, 3, 41)] == [1, 1, 1, 1, 1, 0, 0]      # every h in [4, 40] (round 5)
+    assert [lib.bmpc_supported_horizon(h) for h in (10, 16, 20, 11, 4, 1, 0, 41)] == [1, 1, 1, 1, 1, 1, 0, 0]      # every h in [1, 40] (round 5)
     assert lib.bmpc_default_params(cp, 16) == 0 and cp.half == 8
 
 

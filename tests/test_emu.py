@@ -40,11 +40,11 @@ def test_kernel_source_on_cpu_matches_fixtures(name, idx):
 
 
 @pytest.mark.parametrize("name,key,idx", [("cfg4_walking_h10", None, [3]), ("edge_cases_h10", None, [2]), ("cfg_hgen", 14, [0]),
-                                          ("cfg_hgen", 26, [0]), ("cfg_hodd", 5, [1]), ("cfg_hodd", 9, [2])])
+                                          ("cfg_hgen", 26, [0]), ("cfg_hodd", 5, [1]), ("cfg_hodd", 9, [2]), ("cfg_hodd", 1, [0]), ("cfg_hodd", 3, [3])])
 def test_stage_kernel_source_on_cpu_matches_fixtures(name, key, idx):
     """The stage-structured kernel (bmpc_stage.hip: Riccati recursion, scans over the steps, phantom steps past the
     horizon at h = 14, the two-wave workgroup at h = 26, the DPP row broadcasts of the two passes emulated lane by lane) on
-    the CPU against the fixtures; round 5: odd and short horizons (h = 5: most of the smallest variant's step slots are phantoms)."""
+    the CPU against the fixtures; round 5: odd and short horizons (h = 5: most of the smallest variant's step slots are phantoms; h = 1: all but one)."""
     import __graft_entry__ as ge
     ge.build()
     import biped_mpc_py_amd as bm

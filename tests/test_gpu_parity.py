@@ -1008,23 +1008,23 @@ def _hgen(h, name="cfg_hgen"):
 
 
 def test_every_horizon_is_supported():
-    """REF:24: `h` is a plain field of MPC.  Every horizon in [4, 40] has a kernel (round 5: odd and short ones on the stage
+    """REF:24: `h` is a plain field of MPC.  Every horizon in [1, 40] has a kernel (round 5: odd and short ones on the stage
     family, whose lane map takes any number of steps -- the rest are phantoms); the dense family has the even ones in [8, 20]."""
     from biped_mpc_py_amd import _lib
     lib = _lib.load()
-    for h in range(1, 48):
-        want = 1 if 4 <= h <= 40 else 0
+    for h in range(0, 48):
+        want = 1 if 1 <= h <= 40 else 0
         assert lib.bmpc_supported_horizon(h) == want, h
         assert lib.bmpc_supported_horizon_path(h, PATH_STAGE) == want, h
         assert lib.bmpc_supported_horizon_path(h, PATH_DENSE) == (1 if (8 <= h <= 20 and h % 2 == 0) else 0), h
 
 
-@pytest.mark.parametrize("h", [4, 5, 7, 9, 15, 21, 33])
+@pytest.mark.parametrize("h", [1, 2, 3, 4, 5, 7, 9, 15, 21, 33])
 def test_odd_and_short_horizons(h):
     """REF:24 takes any int.  Odd and short horizons (oracle-solved extension fixtures, 4 instances each: walking with half
-    period h // 2 -- the second touch-down point kept to the end of the horizon --, commanded v_x, per-step friction) run on the
-    stage-structured family: its lane map takes any number of steps (h = 4, 5: most of the smallest variant's slots are
-    phantoms; h = 21: five steps per lane; h = 33: two waves).  AUTO resolves to it."""
+    period max(1, h // 2) -- the second touch-down point kept to the end of the horizon --, commanded v_x, per-step friction) run on
+    the stage-structured family: its lane map takes any number of steps (h = 1: ONE step, nine of the smallest variant's ten
+    slots are phantoms; h = 21: five steps per lane; h = 33: two waves).  AUTO resolves to it."""
     g = _hgen(h, "cfg_hodd")
     for path in (PATH_AUTO, PATH_STAGE):
         solver, mpc = _solver(h, int(g["half"][0]), path=path)
