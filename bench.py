@@ -559,6 +559,38 @@ def run_rank(args):
         solver_b.close()
         return rec
 
+    def ordered_dispatch():
+        """The timed steps again with the instances dispatched longest first, by the iteration counts of the solve before (what a
+        receding-horizon caller has from the previous control period: `bmpc_set_dispatch_order`): a secondary record that sizes the
+        tail of a launch -- the results do not depend on the order."""
+        tin2 = {k: (None if s.get(k) is None or (k == "x_cmd" and not use_x_cmd) else
+                    torch.from_numpy(np.ascontiguousarray(s[k][lo:hi].astype(np.float32) if s[k].dtype == np.float64 else s[k][lo:hi])).to(dev))
+                for k in ("x_fb", "foot", "contact", "phase", "x_cmd", "mu")}
+        out = torch.empty((B, h, 12), dtype=torch.float32, device=dev)
+        it = torch.empty(B, dtype=torch.int32, device=dev)
+        kw = dict(x_cmd=tin2["x_cmd"], mu=tin2["mu"], controls=out, iters=it)
+        solver.solve_device(tin2["x_fb"], tin2["foot"], tin2["contact"], tin2["phase"], **kw)
+        torch.cuda.synchronize(dev)
+        order = torch.argsort(it, descending=True, stable=True).to(torch.int32).contiguous()
+        solver.set_dispatch_order(order)
+        try:
+            for _ in range(max(1, args.warmup)):
+                solver.solve_device(tin2["x_fb"], tin2["foot"], tin2["contact"], tin2["phase"], **kw)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                solver.solve_device(tin2["x_fb"], tin2["foot"], tin2["contact"], tin2["phase"], **kw)
+            torch.cuda.synchronize(dev)
+            t_ord = (time.perf_counter() - t0) / args.steps
+        finally:
+            solver.set_dispatch_order(None)
+        return {"value": B / t_ord, "unit": "solves/s", "ms_per_step": 1e3 * t_ord, "steps": args.steps,
+                "ratio_to_value": (B / t_ord) / (B * args.steps / elapsed),
+                "bit_identical_to_batch_order": bool(torch.equal(out, o_u)),
+                "what": "the same step with the workgroups dispatched by descending iteration count of the previous solve of the same batch "
+                        "(bmpc_set_dispatch_order; roll-outs do it by themselves): what the unequal instances of a batch cost a launch "
+                        "that does not know them (4096 instances on 1024 slots); not `value`"}
+
     strong = args.scaling == "strong"
     path_arg = args.path or ("best" if args.config == 5 else "auto")
     R = timed_run(args.config, strong, path_arg, args.steps, args.warmup, batch=args.batch, total_arg=args.total,
@@ -700,6 +732,12 @@ def run_rank(args):
             except Exception as e:             # a secondary record must not cost the line
                 _log(f"two batches in flight failed: {type(e).__name__}: {e}")
                 line["two_batches_in_flight"] = {"value": None, "unit": "solves/s", "what": f"unavailable in this run: {type(e).__name__}"}
+            _log("dispatch ordered by the previous solve's iteration counts")
+            try:
+                line["ordered_dispatch"] = ordered_dispatch()
+            except Exception as e:
+                _log(f"ordered dispatch failed: {type(e).__name__}: {e}")
+                line["ordered_dispatch"] = {"value": None, "unit": "solves/s", "what": f"unavailable in this run: {type(e).__name__}"}
         _log("host-pointer (PCIe-inclusive) rate")
         # whole-batch wall clock through the host-pointer entries (inputs from host arrays, results in host arrays, fp64 as REF:300-304)
         try:                                       # (a secondary record must not cost the line)

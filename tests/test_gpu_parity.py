@@ -782,6 +782,8 @@ def test_bench_default_line_carries_the_contract_and_the_secondary_records():
     assert line["value_incl_pcie"]["bit_identical_to_device_path"] and line["value_incl_pcie"]["value"] > 0
     two = line["two_batches_in_flight"]
     assert two["bit_identical_to_one_at_a_time"] and two["streams"] == 2 and two["value"] > 0.9 * line["value"]
+    od = line["ordered_dispatch"]                         # (longest first by the previous solve's counts: same results, not slower)
+    assert od["bit_identical_to_batch_order"] and od["value"] > 0.95 * line["value"]
 
 
 @pytest.mark.parametrize("gait", ["standing", "walking"])
