@@ -163,8 +163,8 @@ struct Dims {
   __host__ __device__ static constexpr int lane_of(int row, int f) { return WL ? 64 * (row / RW) + 2 * (row % RW) + f : 2 * row + f; }
   // Waves per SIMD the register allocation aims at.  An instance is a latency-bound chain of LDS exchanges, so a
   // CU's throughput is (instances in flight) / (latency of one); two per SIMD = 4 instances per CU at h = 10.
-  // Three per SIMD (<= 168 registers) was measured with the DPP-broadcast variant of this kernel (DESIGN.md
-  // section 9): 5 instances per CU at h = 10 gained nothing at the 4096-instance batch (the vector pipe was
+  // Three per SIMD (<= 168 registers) was measured with the DPP-broadcast variant of this kernel (docs/
+  // history_r02_r03.md): 5 instances per CU at h = 10 gained nothing at the 4096-instance batch (the vector pipe was
   // then ~80 % busy), h = 16 gained 11 %; this variant needs too many spills for it (155 at h = 16).
   static constexpr int WPE = 2;
   static constexpr int NPAIR = H * (H - 1) / 2;          // (i > j) step pairs

@@ -186,7 +186,7 @@ def test_every_barrier_waits_for_the_waves_lds_operations(isa_text):
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_no_dpp_hazard_behind_inline_asm(isa_text):
-    """Guard for inline-asm DPP instructions (the DPP-broadcast sweep variant of DESIGN.md section 9 used
+    """Guard for inline-asm DPP instructions (the DPP-broadcast sweep variant of docs/history_r02_r03.md used
     `v_fmac_f32_dpp`; the shipped kernel has none, the compiler's own DPP moves are hazard-checked by the
     compiler).  The compiler's hazard recogniser does not look inside
     inline asm, so nothing inserts the two wait states a DPP read needs after a VALU write of the same register.

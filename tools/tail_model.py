@@ -5,7 +5,7 @@ A batch of 4096 instances runs on 1024 instance slots (4 per CU x 256 CUs); work
 slots free up, an instance's duration varies with its iteration and factorisation counts (35-105 iterations at h = 10),
 and the end of the launch waits for the last instances.  This tool measures the per-instance counts of BASELINE config C on
 the GPU, calibrates a small event model of the dispatch (per-CU occupancy slows an instance down: the measured occupancy
-curve of DESIGN.md section 9), and evaluates on the SAME instances:
+curve of docs/history_r04.md), and evaluates on the SAME instances:
 
     as dispatched           the model of today's launch (calibrated to the measured kernel time)
     perfect packing         total work / slots: the floor any reordering or splitting could reach
@@ -26,7 +26,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 SLOTS_PER_CU, CUS = 4, 256
-# relative speed of an instance when k instances share its CU (1 / 2 / 3 / 4 per CU -> 2.33 / 1.37 /
+# relative speed of an instance when k instances share its CU (docs/history_r04.md: 1 / 2 / 3 / 4 per CU -> 2.33 / 1.37 /
 # 1.05 / 0.90 ms per 4096, i.e. per-instance latency 0.146 / 0.171 / 0.197 / 0.225 ms), normalised to 4 per CU
 SPEED = np.array([0.0, 0.225 / 0.146, 0.225 / 0.171, 0.225 / 0.197, 1.0])
 
