@@ -22,7 +22,7 @@ def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_m
     for j, sgn in enumerate((1.0, -1.0)):
         foot[:, 3 * j + 0] = x_fb[:, 3] - 0.0195 + rng.uniform(-0.05, 0.05, B)
         foot[:, 3 * j + 1] = x_fb[:, 4] + sgn * (0.089 + rng.uniform(-0.03, 0.03, B))
-    half = half or (5 if h == 10 else h // 2)
+    half = half or (5 if h == 10 else max(1, h // 2))
     x_cmd = np.tile(np.array([0, 0, 0, 0, 0, 0.55, 0, 0, 0, 0, 0, 0.0]), (B, 1))
     if vx_cmd:
         x_cmd[:, 9] = rng.uniform(-0.5, 0.5, B)

@@ -1,6 +1,6 @@
 """Convergence soaks (GPU box): how many instances of large random batches do not converge, and the worst iteration count.
 
-    python tools/soak.py shapes [--set base|long|stage] [--seeds LO HI]
+    python tools/soak.py shapes [--set base|long|stage|short] [--seeds LO HI]
         random batches of the BASELINE config shapes over a range of seeds (base: the four shapes, 65536 / 16384 per seed;
         long: h = 16 / 20 variants; stage: six long-horizon shapes on the stage-structured kernels, 8192 per seed)
     python tools/soak.py params [--cases Q_x10,R_div100,...] [--rescue off|auto|on] [--paths 1,2] [--horizons 10,20] [--batch N]
@@ -26,6 +26,10 @@ SHAPE_SETS = {
              (20, "walking", dict(vx_cmd=True, per_step_mu=True))),
     "long": ((16, "walking", dict(vx_cmd=True)), (20, "walking", dict(vx_cmd=True, per_step_mu=True)),
              (16, "mixed", dict(vx_cmd=True)), (20, "standing", dict(per_step_mu=True))),
+    # odd and short horizons (stage-structured family; round 5)
+    "short": ((1, "walking", dict(vx_cmd=True)), (2, "mixed", dict(vx_cmd=True)), (3, "walking", dict(vx_cmd=True, per_step_mu=True)),
+              (5, "mixed", dict(vx_cmd=True)), (7, "walking", dict(vx_cmd=True, per_step_mu=True)), (9, "standing", {}),
+              (15, "walking", dict(vx_cmd=True)), (21, "mixed", dict(vx_cmd=True, per_step_mu=True)), (33, "walking", dict(vx_cmd=True))),
     # the stage-structured family: every NP / NW variant, the long horizons twice
     "stage": ((24, "walking", dict(vx_cmd=True, per_step_mu=True)), (28, "mixed", dict(vx_cmd=True)),
               (32, "walking", dict(vx_cmd=True, per_step_mu=True)), (40, "walking", dict(vx_cmd=True, per_step_mu=True)),
