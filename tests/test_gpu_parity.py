@@ -859,7 +859,7 @@ def test_reference_generators_dropin():
 
 
 @pytest.mark.parametrize("h,path", [(10, PATH_STAGE), (16, PATH_STAGE), (32, PATH_AUTO), (40, PATH_AUTO), (7, PATH_AUTO), (15, PATH_AUTO),
-                                    (33, PATH_AUTO)])
+                                    (33, PATH_AUTO), (3, PATH_AUTO)])
 def test_reference_generators_at_every_horizon_and_on_the_stage_family(h, path):
     """`assemble` / `reference_trajectories_batch` (REF:61-109 on the device) at the horizons only the stage family solves,
     and through the stage kernel's own reference branch at h <= 20 (path = STAGE), against the oracle's generators with the
@@ -1038,6 +1038,64 @@ def test_odd_and_short_horizons(h):
         assert (info["status"] == 0).all()
         assert e.max() <= util.REL_TOL and es.max() <= util.REL_TOL
         solver.close()
+
+
+@pytest.mark.parametrize("h", [1, 2, 3])
+def test_tiny_horizons_through_every_entry_point(h):
+    """REF:24 takes any int, h = 1 included (one step: REF:195-216 has a single dynamics row).  The tiny horizons through everything a
+    caller can reach: the host-pointer solve and the in-place I/O block (bit-identical), the oracle, the reference generators, a
+    warm-started closed-loop roll-out on the device (shift = 1 needs two steps) and the reference's own call at h = 1."""
+    import torch
+    import biped_mpc_py_amd as bm
+    from oracle import bmpc_oracle as orc
+    B = 64
+    dev = torch.device("cuda", 0)
+    s = util.synth_batch(B, h, 70 + h, gait="walking", vx_cmd=True)
+    assert s["half"] == 1
+    mpc = bm.MPC()
+    mpc.h = h
+    sol = bm.BatchSolver(mpc=mpc, half=s["half"], max_batch=B)
+    assert sol._lib.bmpc_solver_path(sol._h) == PATH_STAGE
+    st, u, info = sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    st2, u2, _ = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    assert (info["status"] == 0).all() and st.shape == (B, h, 13) and u.shape == (B, h, 12)
+    assert np.array_equal(u, u2) and np.array_equal(st, st2)
+    r32 = lambda v: v.astype(np.float32).astype(float)
+    om = orc.MPC()
+    om.h = h
+    for i in range(6):
+        om.x_cmd = r32(s["x_cmd"][i])
+        t = (s["phase"][i] + 0.5) * om.dt
+        so, co = orc.solve_mpc(r32(s["x_fb"][i]), t, r32(s["foot"][i]), om, orc.Biped(), s["contact"][i], half=s["half"])
+        assert util.rel_err(u[i:i + 1], co[None]).max() <= 1e-5 and util.rel_err(st[i:i + 1], so[None]).max() <= 1e-5, i
+    x_ref, foot_ref, _, _ = sol.assemble(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"], want_matrices=False)
+    for i in range(6):
+        om.x_cmd = r32(s["x_cmd"][i])
+        xr = orc.get_reference_trajectory(r32(s["x_fb"][i]), om)
+        fr = orc.get_reference_foot_trajectory(r32(s["x_fb"][i]), (s["phase"][i] + 0.5) * om.dt, r32(s["foot"][i]), om, s["contact"][i], half=s["half"])
+        assert np.abs(x_ref[i].T - xr[:12]).max() < 1e-6 and np.abs(foot_ref[i].T - fr).max() < 1e-6, i
+    sol.set_warm_start(True, shift=min(1, h - 1), theta=0.5)
+    xt = torch.from_numpy(s["x_fb"].astype(np.float32)).to(dev)
+    ft = torch.from_numpy(s["foot"].astype(np.float32)).to(dev)
+    tt = torch.from_numpy((s["phase"] + 0.5) * mpc.dt).to(dev)
+    out = sol.rollout_device(xt, ft, tt, steps=6)
+    torch.cuda.synchronize()
+    assert int(out["status_any"].sum().item()) == 0 and bool(torch.isfinite(out["u0"]).all().item()) and bool(torch.isfinite(out["x"]).all().item())
+    sol.close()
+    if h == 1:                                   # the reference's own call, one instance
+        bm.close_cached_solvers()
+        x = np.array([0.01, -0.02, 0.03, 0.0, 0.0, 0.5, 0, 0, 0, 0.1, 0, 0.0])
+        foot = np.array([-0.02, 0.09, 0, -0.02, -0.09, 0])
+        stt, ctl = bm.solve_mpc(x, 0.02, foot, mpc, bm.Biped(), bm.get_contact_sequence(0.02, mpc))
+        _, cto = orc.solve_mpc(r32(x), 0.02, r32(foot), _mpc_h(orc, 1), orc.Biped(), orc.get_contact_sequence(0.02, _mpc_h(orc, 1)))
+        assert stt.shape == (1, 13) and ctl.shape == (1, 12) and util.rel_err(ctl[None], cto[None]).max() <= 1e-5
+        bm.close_cached_solvers()
+
+
+def _mpc_h(mod, h):
+    m = mod.MPC()
+    m.h = h
+    return m
 
 
 @pytest.mark.parametrize("name", ["cfg2_standing_h10", "cfg4_walking_h10", "edge_cases_h10", "cfg3_trot_h16", "cfg5_mu_h20",
