@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmpc.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # every symbol include/bmpc.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
@@ -17,7 +17,7 @@ EXPORTS = (
     "bmpc_default_params",
     "bmpc_create", "bmpc_destroy", "bmpc_set_params", "bmpc_get_params",
     "bmpc_solve_batch", "bmpc_solve_batch_f64", "bmpc_solve_batch_device", "bmpc_synchronize",
-    "bmpc_host_io", "bmpc_solve_batch_io",
+    "bmpc_host_io", "bmpc_solve_batch_io", "bmpc_host_io_generation",
     "bmpc_debug_assemble", "bmpc_debug_set_profile", "bmpc_last_kernel_ms",
     "bmpc_foot_position_world", "bmpc_foot_position_world_device",
     "bmpc_low_level_control", "bmpc_low_level_control_device",

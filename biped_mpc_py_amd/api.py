@@ -72,6 +72,24 @@ def _ptr(a):
     return None if a is None else a.__array_interface__["data"][0]
 
 
+class _HandleOwner:
+    """The native handle's lifetime as a Python object: `bmpc_destroy` runs when the LAST reference goes -- the solver's own, or
+    that of an array `solve_inplace` returned.  Those arrays are views of the handle's page-locked I/O block, which
+    `bmpc_destroy` frees; every view keeps this object alive through the buffer it is built on, so closing (or losing) the
+    solver while results are still held defers the destruction instead of leaving them pointing at freed memory."""
+
+    def __init__(self, lib, value):
+        self._lib, self._value = lib, value
+
+    def __del__(self):
+        try:
+            if self._value:
+                self._lib.bmpc_destroy(C.c_void_p(self._value))
+                self._value = None
+        except Exception:
+            pass
+
+
 class BatchSolver:
     """Owns one `bmpc_handle` (device memory + stream) for a fixed parameter block."""
 
@@ -84,6 +102,8 @@ class BatchSolver:
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
         _lib.check(self._lib.bmpc_create(C.byref(self._h), C.byref(self.cparams), self.device, self.max_batch))
+        self._owner = _HandleOwner(self._lib, self._h.value)
+        self._io, self._io_key = None, None
 
     def set_params(self, cparams):
         """Replace the parameter block of this handle (same horizon): `bmpc_set_params`."""
@@ -91,10 +111,12 @@ class BatchSolver:
         self.cparams = cparams
 
     def close(self):
-        self._io, self._io_key = None, None        # (views of the handle's page-locked block: gone with the handle)
-        if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.bmpc_destroy(self._h)
-            self._h = C.c_void_p()
+        """Give the handle up.  It is destroyed at once unless arrays returned by `solve_inplace` are still alive: those are views
+        of the handle's page-locked block, and the native handle (device memory included) then lives until the last of them goes
+        -- copy what must outlive the solver if the memory is to come back now."""
+        self._io, self._io_key = None, None
+        self._owner = None                         # (the last reference unless views are alive: _HandleOwner.__del__ destroys)
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -147,18 +169,25 @@ class BatchSolver:
 
     def _io_views(self, B, with_x_cmd, with_mu, with_states):
         """NumPy views of the handle's page-locked I/O block laid out for batches of B (`bmpc_host_io`); cached per layout."""
-        key = (B, bool(with_x_cmd), bool(with_mu), bool(with_states))
-        if getattr(self, "_io_key", None) == key:
+        # (the key carries the C side's layout generation: a raw bmpc_host_io on this handle, or one that failed part-way,
+        #  moves it, and the cached views -- whose offsets belong to the layout they were made for -- are not trusted any more)
+        key = (B, bool(with_x_cmd), bool(with_mu), bool(with_states), int(self._lib.bmpc_host_io_generation(self._h)))
+        if self._io_key == key:
             return self._io
+        self._io, self._io_key = None, None
         v = _lib.CHostViews()
         _lib.check(self._lib.bmpc_host_io(self._h, B, int(key[1]), int(key[2]), int(key[3]), C.byref(v)))
+        key = key[:4] + (int(self._lib.bmpc_host_io_generation(self._h)),)
         h = self.h
+        owner = self._owner
 
         def view(addr, dtype, shape):
             if not addr:
                 return None
             n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-            return np.frombuffer((C.c_char * n).from_address(addr), dtype=dtype).reshape(shape)
+            buf = (C.c_char * n).from_address(addr)
+            buf._owner = owner                     # the array's base: keeps the native handle alive as long as the view is
+            return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
         self._io = dict(x_fb=view(v.x_fb, np.float32, (B, 12)), foot=view(v.foot, np.float32, (B, 6)),
                         contact=view(v.contact, np.uint8, (B, h, 2)), phase=view(v.phase, np.int32, (B,)),
@@ -171,11 +200,14 @@ class BatchSolver:
 
     def solve_inplace(self, x_fb, foot, contact, phase, x_cmd=None, mu=None, want_states=True):
         """Host arrays in, results IN the solver's own buffers: what a control loop that keeps its arrays wants.  The inputs are
-        converted (fp32) straight into the handle's page-locked I/O block, cross PCIe in one copy, ONE launch solves the batch and
-        the kernels store `states` / `controls` into the block's host arrays, already widened to the reference's fp64
-        (REF:300-304) -- no device-to-host copy and no unpacking pass (`bmpc_host_io` / `bmpc_solve_batch_io`).  Returns
-        (states | None, controls, info) as VIEWS of that block: valid until the next `solve_inplace` of this solver (copy what
-        must outlive it).  Same values as `solve`, bit for bit."""
+        converted (fp32) straight into the handle's page-locked I/O block and cross PCIe in one copy; the batch goes out in up to
+        three chunked launches on prioritised streams; the kernels' epilogues widen to the reference's fp64 (REF:300-304) and store
+        `controls` and the per-instance counters straight into the block's host arrays, `states` are stored in HBM and follow by
+        copy engine chunk by chunk -- except the last chunk's, which go the way of the controls -- so there is no unpacking pass
+        (`bmpc_host_io` / `bmpc_solve_batch_io`, include/bmpc.h).  Returns (states | None, controls, info) as VIEWS of that block:
+        their CONTENT is valid until the next `solve_inplace` of this solver (copy what must outlive it); the MEMORY stays valid
+        as long as a view is held -- the views keep the native handle alive past `close()` / garbage collection of the solver
+        (`_HandleOwner`).  Same values as `solve`, bit for bit."""
         h = self.h
         xf = np.asarray(x_fb)
         B = xf.size // 12
@@ -194,7 +226,10 @@ class BatchSolver:
             np.copyto(io["x_cmd"], np.asarray(x_cmd).reshape(B, 12), casting="same_kind")
         if mu is not None:
             np.copyto(io["mu"], np.asarray(mu).reshape(B, h, 2), casting="same_kind")
-        _lib.check(self._lib.bmpc_solve_batch_io(self._h, B))
+        rc = self._lib.bmpc_solve_batch_io(self._h, B)
+        if rc != 0:
+            self._io, self._io_key = None, None    # (whatever went wrong: the next call lays the block out afresh)
+            _lib.check(rc)
         info = dict(iters=io["iters"], status=io["status"], nfactor=io["nfactor"], residuals=io["residuals"])
         return io["states"], io["controls"], info
 

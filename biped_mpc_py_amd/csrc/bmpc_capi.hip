@@ -280,6 +280,7 @@ struct bmpc_handle_s {
   DevBuf<char> io_dev;
   DevBuf<double> io_states;         // fp64 states of a batch in HBM, on their way to the I/O block by copy engine
   hipEvent_t cev_in = nullptr;      // the I/O block's inputs have arrived
+  int io_gen = 0;                   // moves with every bmpc_host_io call (bmpc_host_io_generation)
   struct IoLayout {
     int B = 0;
     bool x_cmd = false, mu = false, states = false;
@@ -812,6 +813,7 @@ int bmpc_host_io(bmpc_handle h, int B, int with_x_cmd, int with_mu, int with_sta
   const size_t n = (size_t)B, H = (size_t)h->dev.h;
   bmpc_handle_s::IoLayout& L = h->io;
   L.B = 0;
+  h->io_gen = h->io_gen == 0x7fffffff ? 1 : h->io_gen + 1;
   L.i_xfb = 0;
   L.i_foot = align64(L.i_xfb + n * 12 * 4);
   L.i_phase = align64(L.i_foot + n * 6 * 4);
@@ -847,6 +849,11 @@ int bmpc_host_io(bmpc_handle h, int B, int with_x_cmd, int with_mu, int with_sta
   out->nfactor = reinterpret_cast<int32_t*>(o + L.o_nf);
   out->residuals = reinterpret_cast<float*>(o + L.o_rs);
   return BMPC_OK;
+}
+
+int bmpc_host_io_generation(bmpc_handle h) {
+  if (!h) return fail(BMPC_ERR_INVALID, "null handle");
+  return h->io_gen;
 }
 
 int bmpc_solve_batch_io(bmpc_handle h, int B) {

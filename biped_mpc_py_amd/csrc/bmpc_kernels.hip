@@ -1304,8 +1304,12 @@ solve_body(const DevParams& P, const int B,
   // same gamma.  g' is kept from the iteration before the test only; a factorisation in between drops it.
   bool aa_have = false;
   // exact rebuild of the carried products: see the stopping test
-  constexpr int REFRESH_ITERS = 20;
+#ifndef BMPC_REFRESH_ITERS
+#define BMPC_REFRESH_ITERS 20
+#endif
+  constexpr int REFRESH_ITERS = BMPC_REFRESH_ITERS;
   int last_exact = 0;                          // iteration at which gbl, axg were last rebuilt exactly (the start: exact)
+  bool exact_close = false;
   // a stopping test that finds a residual more than FAR times its tolerance away cannot be followed by a
   // successful one check_every iterations later (the tail contracts by ~6 per 5 iterations): the next one is skipped
   constexpr float FAR = 1.0e3f;
@@ -1740,8 +1744,15 @@ solve_body(const DevParams& P, const int B,
         //  1 in 10^4 a decade away from the reference's weights -- otherwise never comes near, drifts, and then cycles for good:
         //  1 of 16384 standing instances at Q x 10 ran into the iteration cap that way, 505 iterations with this)
         constexpr int FAR_REFRESH = 100;
-        const bool rebuild = (nearby && age >= REFRESH_ITERS) || age >= FAR_REFRESH;
-        const bool done = small && slow_ok && age <= REFRESH_ITERS + 2 * check_every;
+#ifndef BMPC_NEAR2
+#define BMPC_NEAR2 0.f
+#endif
+        constexpr float NEAR2 = BMPC_NEAR2;
+        const bool close = NEAR2 > 0.f && !(v5[0] > NEAR2 * tol_p || v5[1] > NEAR2 * tol_s);
+        if (!close) exact_close = false;
+        const bool rebuild = (nearby && age >= REFRESH_ITERS) || age >= FAR_REFRESH || (close && !exact_close && age > 0);
+        const bool done = small && slow_ok && age <= REFRESH_ITERS + 2 * check_every && (NEAR2 == 0.f || exact_close);
+        if (close && rebuild) exact_close = true;
         force_adapt = small && !slow_ok && !bad && it < P.max_iter;
         next_check += far ? 2 * check_every : check_every;
         // (on the way out only the net wrench is needed, for the states: the iterate is what it is)

@@ -7,13 +7,18 @@ from __future__ import annotations
 import numpy as np
 
 
-def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_mu=False):
+def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_mu=False, turn=False):
     """x_fb: euler ~ U(-0.2, 0.2)^3 rad, pos x, y ~ U(-0.5, 0.5), z ~ U(0.45, 0.60), omega ~ U(-0.5, 0.5)^3,
     v ~ U(-0.5, 0.5)^2 x U(-0.2, 0.2); foot_i = (x - 0.0195 + U(-0.05, 0.05), y +- (0.089 + U(-0.03, 0.03)), 0)
     (nominal stance of the reference FK, REF:478-479); x_cmd: REF:26, optionally v_x,cmd ~ U(-0.5, 0.5).
     gait: "standing" (contact = 1, phase 0), "walking" (alternating single support of half period `half`,
     phase ~ U{0..h-1}: generalises REF:52-58) or "mixed" (config 4: standing or any walking phase).
-    per_step_mu: mu[k, foot] ~ U(0.3, 0.9) (config 5).  Returns a dict of fp64 / uint8 / int32 arrays."""
+    per_step_mu: mu[k, foot] ~ U(0.3, 0.9) (config 5).
+    turn (round 6; drawn after everything else, so the batches of the other options keep their draws): commands that take
+    every branch of REF:64-69 -- per Euler angle an angular-rate command x_cmd[6 + i] ~ U(-0.6, 0.6) (70 %; the reference ramps
+    the angle over the horizon, so Rot, R_inv and I_w of REF:148-185 differ at every step) or, with the rate exactly zero, an
+    attitude set-point x_cmd[i] ~ U(-0.2, 0.2); v_y ~ U(-0.3, 0.3) (60 %, else a lateral position set-point U(-0.3, 0.3)),
+    v_z ~ U(-0.15, 0.15) (50 %).  Returns a dict of fp64 / uint8 / int32 arrays."""
     rng = np.random.default_rng(seed)
     x_fb = np.concatenate([
         rng.uniform(-0.2, 0.2, (B, 3)), rng.uniform(-0.5, 0.5, (B, 2)), rng.uniform(0.45, 0.60, (B, 1)),
@@ -38,6 +43,14 @@ def synth_batch(B, h, seed, gait="standing", half=None, vx_cmd=False, per_step_m
             stand = rng.integers(0, h + 1, B) == 0
             contact[stand] = 1
     mu = rng.uniform(0.3, 0.9, (B, h, 2)) if per_step_mu else None
+    if turn:
+        rate = rng.random((B, 3)) < 0.7
+        x_cmd[:, 6:9] = np.where(rate, rng.uniform(-0.6, 0.6, (B, 3)), 0.0)
+        x_cmd[:, 0:3] = np.where(rate, 0.0, rng.uniform(-0.2, 0.2, (B, 3)))
+        lat = rng.random(B) < 0.6
+        x_cmd[:, 10] = np.where(lat, rng.uniform(-0.3, 0.3, B), 0.0)
+        x_cmd[:, 4] = np.where(lat, 0.0, rng.uniform(-0.3, 0.3, B))
+        x_cmd[:, 11] = np.where(rng.random(B) < 0.5, rng.uniform(-0.15, 0.15, B), 0.0)
     return dict(x_fb=x_fb, foot=foot, contact=contact, phase=phase, x_cmd=x_cmd, mu=mu, half=half)
 
 

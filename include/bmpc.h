@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BMPC_ABI_VERSION 10
+#define BMPC_ABI_VERSION 11
 
 /* `stream` arguments are hipStream_t values passed as void*.  NULL is HIP's null (legacy default)
  * stream -- what torch.cuda.current_stream().cuda_stream is when no stream context is active -- so a
@@ -261,6 +261,11 @@ typedef struct bmpc_host_views {
 } bmpc_host_views;
 int bmpc_host_io(bmpc_handle h, int B, int with_x_cmd, int with_mu, int with_states, bmpc_host_views* out);
 int bmpc_solve_batch_io(bmpc_handle h, int B);
+/* Layout generation of the handle's I/O block (ABI 11): a counter that moves with EVERY bmpc_host_io call of the handle, failed
+ * ones included (a failed call leaves no layout: bmpc_solve_batch_io then refuses).  A caller that caches the views compares it
+ * with the value it read after its own bmpc_host_io: any other layout call in between -- same B, other with_* flags, hence other
+ * offsets -- shows, instead of the cached views being trusted.  Returns the counter (>= 0), or a negative error code. */
+int bmpc_host_io_generation(bmpc_handle h);
 
 /*
  * Same, DEVICE pointers (memory of the handle's device), asynchronous on `stream`

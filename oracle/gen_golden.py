@@ -88,11 +88,14 @@ def synth_state(rng):
     return x_fb, foot
 
 
-def run_reference_case(ref, cap, x_fb, t, foot, contact, x_cmd=None):
-    """One call of the reference's own solve_mpc (REF:187) with capture; returns fixture dict."""
+def run_reference_case(ref, cap, x_fb, t, foot, contact, x_cmd=None, bounds=None):
+    """One call of the reference's own solve_mpc (REF:187) with capture; returns fixture dict.
+    bounds: optional dict of Biped fields f_max / f_min / tau_max / tau_min (REF:45-48) as 3-vectors."""
     mpc, biped = ref.MPC(), ref.Biped()
     if x_cmd is not None:
         mpc.x_cmd = np.array(x_cmd, float)
+    for name, v in (bounds or {}).items():
+        setattr(biped, name, np.array(v, float).reshape(3, 1))          # the reference's own 3 x 1 column layout
     with contextlib.redirect_stdout(io.StringIO()):
         states, controls = ref.solve_mpc(np.array(x_fb, float), t, np.array(foot, float), mpc, biped,
                                          np.array(contact))
@@ -114,6 +117,8 @@ def run_reference_case(ref, cap, x_fb, t, foot, contact, x_cmd=None):
               polished=np.int32(c["info"]["polished"]),
               kkt=np.array([c["info"]["kkt"][k] for k in
                             ("stationarity", "primal_eq", "primal_ineq", "dual", "complementarity")]))
+    for name in ("f_max", "f_min", "tau_max", "tau_min"):
+        fx[name] = np.array(getattr(biped, name), float).reshape(3)
     for name in ("P", "G", "A"):
         idx, val = sparse_triplets(c[name])
         fx[name + "_idx"], fx[name + "_val"] = idx, val
@@ -144,9 +149,82 @@ def stack_batch(cases, keys):
     return {k: np.stack([c[k] for c in cases]) for k in keys}
 
 
+REGIME_KEYS = ("x_fb", "t", "foot", "contact", "x_cmd", "x_ref", "foot_ref", "A_k", "B_k", "q", "h",
+               "b", "states", "controls", "objective", "n_pinned", "n_active", "polished", "kkt",
+               "f_max", "f_min", "tau_max", "tau_min")
+
+
+def draw_command(rng, full=True):
+    """A command vector that takes every branch of REF:64-69: per coordinate i < 6 either a rate x_cmd[i + 6] != 0 (the
+    reference ramps x_fb[i] + rate k dt: Euler ramps make Rot, R_inv, I_w differ at EVERY step of the horizon) or, with the rate
+    exactly zero, a set-point x_cmd[i]."""
+    x_cmd = np.array([0, 0, 0, 0, 0, 0.55, 0, 0, 0, 0, 0, 0], float)
+    for i in range(3):                                   # attitude: angular-rate command or set-point
+        if rng.random() < 0.7:
+            x_cmd[6 + i] = rng.uniform(-0.6, 0.6)
+        else:
+            x_cmd[i] = rng.uniform(-0.2, 0.2)
+    if full:
+        for i, (vr, pr) in enumerate(((0.5, 0.3), (0.3, 0.3), (0.15, 0.0))):     # v_x, v_y, v_z commands or position set-points
+            if rng.random() < 0.6:
+                x_cmd[9 + i] = rng.uniform(-vr, vr)
+            elif pr:
+                x_cmd[3 + i] = rng.uniform(-pr, pr)
+    return x_cmd
+
+
+def gen_regimes(ref, cap):
+    """regimes the unpatched reference produces and no earlier fixture held -- generated by the
+    reference's OWN solve_mpc (REF:187; extension = 0).
+      cfg_cmd_h10    80 instances: commanded angular rates / attitude set-points / lateral and vertical velocity commands
+                     (REF:64-69), standing + every walking phase: the per-step linearisation REF:148-185 at x_ref[:, k] sees a
+                     different Rot, R_inv and I_w at every step.
+      cfg_bounds_h10 48 instances: Biped bounds off their defaults (REF:45-48): f_min < 0 on the horizontal axes (a real friction
+                     pyramid), tau_max[0] != 0 (m_x un-pinned), asymmetric tau_min; commands as above on half of them."""
+    mpc0 = ref.MPC()
+    rng = np.random.default_rng(600)
+    cases = []
+    for i in range(80):
+        x_fb, foot = synth_state(rng)
+        if i < 20:                                      # standing
+            t, contact = 0.0, np.ones((10, 2))
+        else:                                           # every walking phase six times
+            k = (i - 20) % 10
+            t = k * mpc0.dt + 0.5 * mpc0.dt
+            contact = ref.get_contact_sequence(t, mpc0)
+        cases.append(run_reference_case(ref, cap, x_fb, t, foot, contact, x_cmd=draw_command(rng)))
+    np.savez_compressed(os.path.join(OUT, "cfg_cmd_h10.npz"), **stack_batch(cases, REGIME_KEYS))
+    print("cfg_cmd max kkt", np.max([c["kkt"] for c in cases], axis=0), "polished", all(c["polished"] for c in cases))
+
+    rng = np.random.default_rng(601)
+    variants = (
+        dict(f_min=[-500, -500, 0]),
+        dict(tau_max=[20, 67, 33.5], tau_min=[-20, -67, -33.5]),
+        dict(tau_min=[0, -30, -10]),                                            # asymmetric moment box (m_x still pinned)
+        dict(f_min=[-500, -500, 0], tau_max=[20, 67, 33.5], tau_min=[-12, -40, -33.5]),
+    )
+    cases = []
+    for i in range(48):
+        x_fb, foot = synth_state(rng)
+        if i % 3 == 0:
+            t, contact = 0.0, np.ones((10, 2))
+        else:
+            k = int(rng.integers(0, 10))
+            t = k * mpc0.dt + 0.5 * mpc0.dt
+            contact = ref.get_contact_sequence(t, mpc0)
+        x_cmd = draw_command(rng) if i % 2 else np.array(mpc0.x_cmd, float)
+        cases.append(run_reference_case(ref, cap, x_fb, t, foot, contact, x_cmd=x_cmd, bounds=variants[i % 4]))
+    np.savez_compressed(os.path.join(OUT, "cfg_bounds_h10.npz"), **stack_batch(cases, REGIME_KEYS))
+    print("cfg_bounds max kkt", np.max([c["kkt"] for c in cases], axis=0), "polished", all(c["polished"] for c in cases),
+          "n_pinned", sorted(set(int(c["n_pinned"]) for c in cases)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref, cap = load_reference()
+    if "--regimes" in sys.argv:                          # only the round-6 regime batches (the other fixtures regenerate bit for bit)
+        gen_regimes(ref, cap)
+        return
     mpc0, biped0 = ref.MPC(), ref.Biped()
 
     # ---- 1. the two known-answer cases, with full matrices and the consumer's tau -------------
@@ -243,6 +321,8 @@ def main():
             cases.append(run_extension_case(x_fb, t, foot, contact, h, h // 2, x_cmd, mu))
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **stack_batch(cases, ekeys))
         print(name, "max kkt", np.max([c["kkt"] for c in cases], axis=0))
+
+    gen_regimes(ref, cap)
 
 
 if __name__ == "__main__":

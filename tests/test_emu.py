@@ -17,7 +17,10 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(emu.CLANG) or shutil.which(e
 
 
 @pytest.mark.parametrize("name,idx", [("cfg4_walking_h10", [3, 17]), ("edge_cases_h10", [0, 4]), ("cfg2_standing_h10", [5]),
-                                      ("cfg3_trot_h16", [2]), ("cfg5_mu_h20", [1])])
+                                      ("cfg3_trot_h16", [2]), ("cfg5_mu_h20", [1]),
+                                      # round 6: turning / attitude commands (standing, walking); bounds off their defaults (variant 3 of
+                                      # gen_regimes: f_min < 0, m_x free, asymmetric tau_min -- one parameter block per call)
+                                      ("cfg_cmd_h10", [5, 44]), ("cfg_bounds_h10", [3, 7])])
 def test_kernel_source_on_cpu_matches_fixtures(name, idx):
     import __graft_entry__ as ge
     ge.build()
@@ -26,7 +29,7 @@ def test_kernel_source_on_cpu_matches_fixtures(name, idx):
     d = util.load(name)
     mpc = bm.MPC()
     mpc.h = h
-    cp = bm.pack_params(mpc, bm.Biped(), half=half)
+    cp = bm.pack_params(mpc, util.biped_of(d, idx[0], bm), half=half)
     mu = d["mu_steps"][idx] if "mu_steps" in d.files and d["mu_steps"].size else None
     o = emu.solve(cp, d["x_fb"][idx], d["foot"][idx], d["contact"][idx], util.phases(d["t"][idx], mpc.dt, h),
                   x_cmd=d["x_cmd"][idx], mu=mu)
@@ -39,7 +42,7 @@ def test_kernel_source_on_cpu_matches_fixtures(name, idx):
         assert np.abs(o["foot_ref"].transpose(0, 2, 1) - d["foot_ref"][idx]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name,key,idx", [("cfg4_walking_h10", None, [3]), ("edge_cases_h10", None, [2]), ("cfg_hgen", 14, [0]),
+@pytest.mark.parametrize("name,key,idx", [("cfg4_walking_h10", None, [3]), ("edge_cases_h10", None, [2]), ("cfg_cmd_h10", None, [61]), ("cfg_bounds_h10", None, [11]), ("cfg_hgen", 14, [0]),
                                           ("cfg_hgen", 26, [0]), ("cfg_hodd", 5, [1]), ("cfg_hodd", 9, [2]), ("cfg_hodd", 1, [0]), ("cfg_hodd", 3, [3])])
 def test_stage_kernel_source_on_cpu_matches_fixtures(name, key, idx):
     """The stage-structured kernel (bmpc_stage.hip: Riccati recursion, scans over the steps, phantom steps past the
@@ -54,7 +57,7 @@ def test_stage_kernel_source_on_cpu_matches_fixtures(name, key, idx):
     half = 5 if key is None else int(d["half"][0])
     mpc = bm.MPC()
     mpc.h = h
-    cp = bm.pack_params(mpc, bm.Biped(), half=half, solver_options=dict(path=2))
+    cp = bm.pack_params(mpc, util.biped_of(d, idx[0], bm) if key is None else bm.Biped(), half=half, solver_options=dict(path=2))
     mu = d["mu_steps"][idx] if "mu_steps" in d and d["mu_steps"].size else None
     o = emu.solve(cp, d["x_fb"][idx], d["foot"][idx], d["contact"][idx], util.phases(d["t"][idx], mpc.dt, h),
                   x_cmd=d["x_cmd"][idx], mu=mu)

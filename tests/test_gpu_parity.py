@@ -12,21 +12,38 @@ pytestmark = pytest.mark.gpu
 PATH_AUTO, PATH_DENSE, PATH_STAGE = 0, 1, 2
 
 
-def _solver(h, half, **opts):
+def _solver(h, half, biped=None, **opts):
     import biped_mpc_py_amd as bm
     mpc = bm.MPC()
     mpc.h = h
-    return bm.BatchSolver(mpc=mpc, half=half, solver_options=opts or None), mpc
+    return bm.BatchSolver(mpc=mpc, biped=biped, half=half, solver_options=opts or None), mpc
+
+
+def _solve_fixture(d, h, half, **opts):
+    """A batch fixture through `BatchSolver.solve`, one handle per group of instances generated with the same Biped bounds
+    (REF:45-48; one group -- the defaults -- for every fixture but cfg_bounds_h10).  Returns (states, controls, info, solvers)."""
+    import biped_mpc_py_amd as bm
+    n = d["x_fb"].shape[0]
+    mu = d["mu_steps"] if "mu_steps" in d.files and d["mu_steps"].size else None
+    states, controls = np.empty((n, h, 13)), np.empty((n, h, 12))
+    info = {k: np.empty(n, np.int32) for k in ("iters", "status", "nfactor")}
+    solvers = []
+    for idx, biped in util.bounds_groups(d, bm):
+        solver, mpc = _solver(h, half, biped=biped, **opts)
+        st, u, inf = solver.solve(d["x_fb"][idx], d["foot"][idx], d["contact"][idx], util.phases(d["t"][idx], mpc.dt, h),
+                                  x_cmd=d["x_cmd"][idx], mu=None if mu is None else mu[idx])
+        states[idx], controls[idx] = st, u
+        for k in info:
+            info[k][idx] = inf[k]
+        solvers.append(solver)
+    return states, controls, info, solvers
 
 
 @pytest.mark.parametrize("name", list(util.BATCH_FIXTURES))
 def test_golden_batches(name):
     h, half = util.BATCH_FIXTURES[name]
     d = util.load(name)
-    solver, mpc = _solver(h, half)
-    mu = d["mu_steps"] if "mu_steps" in d.files and d["mu_steps"].size else None
-    states, controls, info = solver.solve(d["x_fb"], d["foot"], d["contact"], util.phases(d["t"], mpc.dt, h),
-                                          x_cmd=d["x_cmd"], mu=mu)
+    states, controls, info, _ = _solve_fixture(d, h, half)
     e = util.rel_err(controls, d["controls"])
     es = util.rel_err(states, d["states"])
     print(name, "ctrl err max %.2e  state err max %.2e  iters mean %.1f max %d  nfactor mean %.1f" %
@@ -474,9 +491,11 @@ def test_solve_device_is_ordered_on_the_default_stream():
 @pytest.mark.parametrize("B,h,kw", [(4099, 10, dict(vx_cmd=True)), (1023, 10, {}), (5, 10, {}), (2051, 20, dict(vx_cmd=True, per_step_mu=True))])
 def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
     """`bmpc_solve_batch` / `bmpc_solve_batch_f64` (what REF:487 callers get): pinned staging, up to three chunks on streams of
-    descending priority, the kernels storing their results straight into the mapped pinned block, a chunk's unpacking / fp64
-    widening overlapped with the later chunks' solves; and `bmpc_host_io` / `bmpc_solve_batch_io` (round 5): the handle's
-    page-locked I/O block, one copy in, one launch, fp64 results stored by the kernels into the block's host arrays.  The
+    descending priority, each chunk's results written to HBM and followed on its stream by one packed device-to-host copy into
+    pinned memory, a chunk's unpacking / fp64 widening overlapped with the later chunks' solves; and `bmpc_host_io` /
+    `bmpc_solve_batch_io` (round 5): the handle's page-locked I/O block, one copy in, up to three chunked launches, fp64 controls
+    and counters stored by the kernels straight into the block's host arrays, states by copy engine per chunk (the last chunk's
+    by the kernel).  The
     results must not depend on any of that: every entry against ONE launch of `bmpc_solve_batch_device` over the whole batch,
     bit for bit -- controls, states, iteration counts, status, residuals -- for ragged sizes (chunk boundaries off any power
     of two, fewer instances than a chunk), optional inputs, `want_states = False`, caller-owned output arrays, and with a
@@ -547,7 +566,7 @@ def test_host_pointer_path_is_chunked_and_bit_identical(B, h, kw):
     u_c = np.frombuffer((C.c_char * (B * h * 12 * 8)).from_address(v.controls), np.float64).reshape(B, h, 12)
     assert np.array_equal(u_c, u)
     assert sol._lib.bmpc_solve_batch_io(sol._h, B + 1) != 0                 # (laid out for B: anything else is refused)
-    sol._io_key = None                                                      # (the raw call re-laid the block: drop the cached views)
+    # (the raw call re-laid the block: the wrapper sees the layout generation move and re-reads its views by itself)
     # a dispatch order indexes the whole batch: one chunk, same results
     order = torch.arange(B - 1, -1, -1, dtype=torch.int32, device=dev)
     sol.set_dispatch_order(order)
@@ -582,6 +601,53 @@ def test_io_block_edges():
     st1, u1, _ = sol.solve_inplace(k["x_fb"][None], k["foot"][None], k["contact"][None], np.array([util.phases(np.array([float(k["t"])]), 0.04, 10)[0]]))
     assert util.rel_err(u1, k["controls"][None]).max() <= util.REL_TOL
     sol.close()
+
+
+def test_io_views_outlive_the_solver_and_a_foreign_layout_call_is_noticed():
+    """ADVICE r5.  (medium) The arrays `solve_inplace` returns are views of the handle's page-locked block, which `bmpc_destroy`
+    frees: they keep the native handle alive (`api._HandleOwner`), so results held past `close()` -- or past the solver object
+    itself, `BatchSolver(...).solve_inplace(...)` -- still read the results, not freed memory; the handle goes with the last
+    view.  (low) The wrapper's cached views belong to ONE layout: a raw `bmpc_host_io` on the same handle with the same B and
+    other flags moves the offsets; the layout generation (`bmpc_host_io_generation`, ABI 11) shows it and the next
+    `solve_inplace` re-reads the views instead of writing its inputs at stale offsets."""
+    import ctypes as C
+    import gc
+    import weakref
+    import biped_mpc_py_amd as bm
+    from biped_mpc_py_amd import _lib
+    s = util.synth_batch(700, 10, 4242, gait="mixed", vx_cmd=True)
+    ref_sol = bm.BatchSolver(max_batch=700)
+    st, u, info = ref_sol.solve(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    # results of a temporary solver
+    st_t, u_t, i_t = bm.BatchSolver(max_batch=700).solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    gc.collect()
+    assert np.array_equal(u_t, u) and np.array_equal(st_t, st) and np.array_equal(i_t["iters"], info["iters"])
+    # results held past close(); the handle is destroyed when the last view goes
+    sol = bm.BatchSolver(max_batch=700)
+    owner = weakref.ref(sol._owner)
+    st_i, u_i, i_i = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    sol.close()
+    gc.collect()
+    assert owner() is not None and np.array_equal(u_i, u) and np.array_equal(st_i, st)
+    with pytest.raises(Exception):
+        sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])          # a closed solver refuses
+    del st_i, u_i, i_i
+    gc.collect()
+    assert owner() is None
+    # a foreign layout call between two in-place solves
+    sol = bm.BatchSolver(max_batch=700)
+    _, u_a, _ = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    assert np.array_equal(u_a, u)
+    g0 = sol._lib.bmpc_host_io_generation(sol._h)
+    v = _lib.CHostViews()
+    assert sol._lib.bmpc_host_io(sol._h, 700, 0, 1, 0, C.byref(v)) == 0          # same B, other flags: other offsets
+    assert sol._lib.bmpc_host_io_generation(sol._h) == g0 + 1
+    st_b, u_b, _ = sol.solve_inplace(s["x_fb"], s["foot"], s["contact"], s["phase"], x_cmd=s["x_cmd"])
+    assert np.array_equal(u_b, u) and np.array_equal(st_b, st)
+    assert sol._lib.bmpc_host_io(sol._h, 701, 0, 0, 1, C.byref(v)) != 0          # refused before anything moved: the layout stands
+    assert sol._lib.bmpc_host_io_generation(sol._h) == g0 + 2
+    sol.close()
+    ref_sol.close()
 
 
 def test_dropin_reuses_one_handle_and_reports_status():
@@ -1099,7 +1165,7 @@ def _mpc_h(mod, h):
 
 
 @pytest.mark.parametrize("name", ["cfg2_standing_h10", "cfg4_walking_h10", "edge_cases_h10", "cfg3_trot_h16", "cfg5_mu_h20",
-                                  "cfg_h32", "cfg_h40"])
+                                  "cfg_cmd_h10", "cfg_bounds_h10", "cfg_h32", "cfg_h40"])
 def test_stage_path_golden_batches(name):
     """The stage-structured kernels against the same certified optima as the dense ones (and the long-horizon
     extension fixtures only they can solve): <= 1e-4, every instance converged, and -- where both families exist --
@@ -1107,11 +1173,8 @@ def test_stage_path_golden_batches(name):
     d = util.load(name)
     h = int(d["hor"][0]) if "hor" in d.files else 10
     half = int(d["half"][0]) if "half" in d.files else 5
-    mu = d["mu_steps"] if "mu_steps" in d.files and d["mu_steps"].size else None
-    solver, mpc = _solver(h, half, path=PATH_STAGE)
-    assert solver._lib.bmpc_solver_path(solver._h) == PATH_STAGE
-    ph = util.phases(d["t"], mpc.dt, h)
-    states, controls, info = solver.solve(d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"], mu=mu)
+    states, controls, info, solvers = _solve_fixture(d, h, half, path=PATH_STAGE)
+    assert all(s._lib.bmpc_solver_path(s._h) == PATH_STAGE for s in solvers)
     e, es = util.rel_err(controls, d["controls"]), util.rel_err(states, d["states"])
     print(name, "stage path: ctrl err max %.2e state err max %.2e iters mean %.1f max %d nfactor %.2f" %
           (e.max(), es.max(), info["iters"].mean(), info["iters"].max(), info["nfactor"].mean()))
@@ -1119,11 +1182,9 @@ def test_stage_path_golden_batches(name):
     assert e.max() <= util.REL_TOL and es.max() <= util.REL_TOL
     if h <= 20:
         # the plain method (secant extrapolation off: it amplifies last-bit differences into different paths) on both families
-        plain, _ = _solver(h, half, path=PATH_STAGE, accel=0)
-        _, _, info = plain.solve(d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"], mu=mu)
-        dense, _ = _solver(h, half, path=PATH_DENSE, accel=0)
-        assert dense._lib.bmpc_solver_path(dense._h) == PATH_DENSE
-        _, _, info_d = dense.solve(d["x_fb"], d["foot"], d["contact"], ph, x_cmd=d["x_cmd"], mu=mu)
+        _, _, info, _ = _solve_fixture(d, h, half, path=PATH_STAGE, accel=0)
+        _, _, info_d, dense = _solve_fixture(d, h, half, path=PATH_DENSE, accel=0)
+        assert all(s._lib.bmpc_solver_path(s._h) == PATH_DENSE for s in dense)
         assert np.abs(info["iters"].astype(int) - info_d["iters"]).max() <= 10          # (f32 preconditioners differ in the last bits)
         assert abs(info["iters"].mean() - info_d["iters"].mean()) <= 2.0
     else:
@@ -1257,7 +1318,10 @@ def test_parameter_range_vs_oracle(what):
 
 
 @pytest.mark.parametrize("name,h,half,idx", [("cfg4_walking_h10", 10, 5, [0, 5, 11, 23, 40, 63]), ("cfg3_trot_h16", 16, 8, [0, 7, 19]),
-                                             ("cfg5_mu_h20", 20, 10, [1, 9, 15])])
+                                             ("cfg5_mu_h20", 20, 10, [1, 9, 15]),
+                                             # round 6: commanded angular rates / attitudes -- Rot, R_inv, I_w differ at every step, so the prefix
+                                             # sums P_i, the Me table and the Gram M'M on the matrix cores see non-identity steps
+                                             ("cfg_cmd_h10", 10, 5, [0, 7, 19, 20, 33, 46, 58, 79])])
 def test_assembly_is_the_condensed_qp_of_the_oracle(name, h, half, idx):
     """the kernel's OWN assembly output against the oracle directly, no model of the product in
     between: Hc = Wbar' Gt Wbar + 2 Rbar and gc = Wbar' qt formed from what bmpc_debug_assemble returns (Gt, qt and the
@@ -1334,7 +1398,16 @@ def _oracle_worker(a):
 _AT_SCALE = [("config2_standing_h10", 8192, 10, "standing", 31, {}),
              ("config4_mixed_h10", 8192, 10, "mixed", 3, dict(vx_cmd=True)),
              ("config3_trot_h16", 4096, 16, "walking", 2, dict(vx_cmd=True)),
-             ("config5_mu_h20", 4096, 20, "walking", 4, dict(vx_cmd=True, per_step_mu=True))]
+             ("config5_mu_h20", 4096, 20, "walking", 4, dict(vx_cmd=True, per_step_mu=True)),
+             # round 6: turning / attitude / lateral commands -- REF:64-69's rate branches for the Euler angles, so the
+             # linearisation REF:148-185 differs at every step of the horizon -- at the three BASELINE horizons
+             ("turning_mixed_h10", 4096, 10, "mixed", 61, dict(vx_cmd=True, turn=True)),
+             ("turning_trot_h16", 4096, 16, "walking", 62, dict(vx_cmd=True, turn=True)),
+             ("turning_mu_h20", 4096, 20, "walking", 63, dict(vx_cmd=True, per_step_mu=True, turn=True))]
+
+
+# regression bounds (all controls, u0) of the batches that do not sit at the common 1e-5 / 2e-5
+_AT_SCALE_BOUNDS = {"turning_trot_h16": (3e-5, 5e-5), "turning_mu_h20": (3e-5, 5e-5)}
 
 
 @pytest.mark.parametrize("label,B,h,gait,seed,kw", _AT_SCALE, ids=[a[0] for a in _AT_SCALE])
@@ -1373,8 +1446,10 @@ def test_parity_against_the_oracle_at_scale(label, B, h, gait, seed, kw):
                   int((info["status"] != 0).sum())))
         assert (info["status"] == 0).all()
         assert e.max() <= util.REL_TOL and e0.max() <= util.REL_TOL
-        # regression bounds well inside the tolerance (measured on MI355X: profiles/r04_parity_at_scale.txt)
-        assert e.max() <= 1e-5 and e0.max() <= 2e-5, (e.max(), e0.max())
+        # regression bounds well inside the tolerance (measured on MI355X: profiles/r04_parity_at_scale.txt; the turning batches of
+        # round 6: profiles/r06_parity_at_scale.txt)
+        b_all, b_u0 = _AT_SCALE_BOUNDS.get(label, (1e-5, 2e-5))
+        assert e.max() <= b_all and e0.max() <= b_u0, (e.max(), e0.max())
 
 
 # BASELINE's full sizes (configs[3], configs[4]): (label, config number, instances checked against the oracle)
