@@ -131,6 +131,8 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
     if (!(p.R[i] > 0) || !(p.Q[i] >= 0)) return fail(BMPC_ERR_INVALID, "need R > 0, Q >= 0");
   }
   for (int k = 0; k < 3; ++k) { d->sq_e[k] = std::sqrt(2.0 * p.Q[k]); d->sq_w[k] = p.dt * std::sqrt(2.0 * p.Q[6 + k]); }
+  d->kpm = p.dt * p.dt / p.m;
+  d->kvm = p.dt / p.m;
   if (!inv3(p.I, d->Iinv)) return fail(BMPC_ERR_INVALID, "inertia matrix is singular");
   for (int i = 0; i < 3; ++i) {
     d->f_max[i] = p.f_max[i]; d->f_min[i] = p.f_min[i];
@@ -182,6 +184,14 @@ int make_dev_params(const bmpc_params& p, bmpc::DevParams* d) {
   d->rho_lo = (float)rho_lo;
   d->rho_hi_f = (float)hi_f; d->rho_hi_m = (float)hi_m;
   d->eps_pri = (float)p.eps_pri; d->eps_dua = (float)p.eps_dua; d->kappa = (float)p.kappa;
+  {                                           // (f32 products exactly as the kernels used to form them: SLOW_TOL = 1e-6, U0_TOL = 5)
+    const float slow_tol = 1.0e-6f, u0_tol = 5.f;
+    d->kappa_sqrt = std::sqrt(d->kappa);
+    d->kappa_qrt = std::sqrt(std::sqrt(d->kappa));
+    d->slow_tol_r2 = slow_tol * d->r2min;
+    d->slow_tol_r2_u0 = u0_tol * slow_tol * d->r2min;
+    d->eps_u0 = u0_tol * std::fmax(d->eps_pri, d->eps_dua);
+  }
   return BMPC_OK;
 }
 

@@ -80,6 +80,8 @@ __device__ __forceinline__ int sync_workgroup_or(int v) {
 #define BMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 // a condition every lane of the wave evaluates alike, as a scalar (the branch on it is a scalar branch)
 #define BMPC_UNIFORM(x) (__builtin_amdgcn_readfirstlane((int)(x)) != 0)
+// an integer every lane of the wave computes alike, as a scalar (loop bounds on it make a scalar loop)
+#define BMPC_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
 __device__ __forceinline__ double widen(float v) { BMPC_OPAQUE(v); return (double)v; }
 __device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap_i(__float_as_int(v))); }
@@ -108,6 +110,12 @@ struct DevParams {
   double dt, kv, m, g, mu, lt, lh, alpha;      // lt, lh already carry the REF:254-255 margins
   double x_cmd[12], Q[12], R2[12], Iinv[9];    // R2 = 2 R;  Iinv = inverse body inertia
   double sq_e[3], sq_w[3];                     // sqrt(2 Q_euler), dt sqrt(2 Q_omega): the row scales of the Hessian-block GEMM (set-up)
+  // uniform f32 values of the stopping test and the re-classification, formed once on the host (gfx950 has no scalar float unit:
+  // formed in the kernel they are loop invariants in VECTOR registers -- the h = 20 kernel spilled six of them)
+  float kappa_sqrt, kappa_qrt;                 // sqrt(kappa), sqrt(sqrt(kappa)): the damped moves after 10 / 16 factorisations
+  float slow_tol_r2, slow_tol_r2_u0, eps_u0;   // SLOW_TOL 2 R_min;  U0_TOL times that;  U0_TOL max(eps_pri, eps_dua)
+  double kpm, kvm;                             // dt^2 / m, dt / m (formed once on the host: two IEEE f64 divisions per lane otherwise, and
+                                               //   four registers a lane kept -- or spilled -- across the iteration loop for the rebuilds)
   double f_max[3], f_min[3], tau_max[3], tau_min[3];
   float rho, rho_eq, rho_lo, rho_hi_f, rho_hi_m, eps_pri, eps_dua, kappa;
   int accel;                                   // secant extrapolation of the iterate at the stopping tests (dense family)
@@ -521,7 +529,16 @@ solve_body(const DevParams& P, const int B,
   long long t_start = 0, t_setup = 0, t_blocks = 0, t_sweep = 0, t_mark = 0;
   long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0, t_red = 0, t_reb = 0;   // (t_red, t_reb: inside t_ph[6], the iteration's tail)
   int n_reb = 0;
+  // (tools only: built with -DBMPC_PROF_BLOCKS the seven phase slots of the diagnostics kernel hold the stages of the 6x6 block
+  //  algebra of factor() instead of the iteration's phases -- tools/phase_cycles.py --blocks)
+#ifdef BMPC_PROF_BLOCKS
+#define BMPC_STAMP(k)
+#define BMPC_BSTAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_mark2; t_mark2 = t_; }
+  long long t_mark2 = 0;
+#else
 #define BMPC_STAMP(k) if constexpr (PROF) { const long long t_ = clock64(); t_ph[k] += t_ - t_last; t_last = t_; }
+#define BMPC_BSTAMP(k)
+#endif
   if constexpr (PROF) t_start = clock64();
   const int l = threadIdx.x;
   const int hf = l & 1;                        // column half of V / Gt, and the foot this lane owns
@@ -691,12 +708,12 @@ solve_body(const DevParams& P, const int B,
   auto gradient_exact = [&](const bool have_b) -> RT {
     // (through opaque copies of the lane's indices: none of the address arithmetic below is hoisted out of the
     // iteration loop, where it would hold registers between two rebuilds)
-    int c = c_lane, j = j_lane, hf = hf_lane;
-    BMPC_OPAQUE(c);
-    BMPC_OPAQUE(j);
+    int rw_ = row, hf = hf_lane;               // (step and component formed again from the row: no copy of them kept for this)
+    BMPC_OPAQUE(rw_);
     BMPC_OPAQUE(hf);
+    const int j = rw_ / 6, c = rw_ - 6 * j;
     const int a = c < 3 ? c : c - 3;
-    const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
+    const RT kp = (RT)P.kpm, kvv = (RT)P.kvm;
     // Every sum has the form  sum_l (C - tab[l]) src[l]  with a row of the coefficient table CT:
     //   rows 0..8  P[a][b] over the steps   (euler: dt (P_j - P_l)[a][b] y_l,b;  adjoint: dt (P_i - P_j)[b][a] q_e,i,b)
     //   row 9      l                        (position: dt^2/m (j - l) F_l)
@@ -704,6 +721,22 @@ solve_body(const DevParams& P, const int B,
     // so one loop serves all lane kinds (they sit in the same wave); coefficients are differences formed term by term,
     // never a difference of sums.  The euler sums have three such terms (b = 0, 1, 2): the two lanes of a torque row
     // share them -- lane 0 takes b = 0, 1, lane 1 its own plain sum and b = 2 -- so no lane runs more than two.
+    // Both sums of a stage in ONE loop over the steps, two steps per trip (round 6): four table entries and four source entries
+    // are in flight together, where a loop per sum with the lane's own bounds paid one LDS round trip per step and sum.  The
+    // bounds are the wave's (the steps its lanes own: wj0 .. wj1), a lane masks the steps outside its own range -- exact zeros,
+    // and the terms are added in the same order, so the sums are the same to the bit.  Force lanes have one sum: their second
+    // one repeats the first and is dropped.  (Fully unrolled over the horizon -- every load of a stage in flight at once -- the
+    // kernels spill: 47 registers at h = 10, 166 at h = 20.)  Up to h = 16; see FUSED below.
+    constexpr int SU = H <= 12 ? 2 : 1;
+    constexpr bool FUSED = H <= 12;
+    int wj0 = 0, wj1 = 0;
+    if constexpr (FUSED) {
+      const int wv_ = l >> 6;
+      wj0 = BMPC_UNIFORM_INT(Dims<H>::WL ? Dims<H>::SW * wv_ : (32 * wv_) / 6);
+      wj1 = BMPC_UNIFORM_INT(Dims<H>::WL ? Dims<H>::SW * wv_ + Dims<H>::SW - 1 : ((32 * wv_ + 31 < NW - 1 ? 32 * wv_ + 31 : NW - 1) / 6));
+    }
+    // (up to h = 12, two steps per trip; from h = 14 on the fused loop costs spilled registers -- 1 at h = 14, 4 .. 26 at h = 16, more
+    //  beyond -- and those horizons keep one loop per sum with the lane's own bounds)
     auto scan = [&](const int rb, const RT* src, const int lo, const int hi) -> RT {
       const RT* tb = &sm.CT[rb][0];
       const RT Cb = tb[j] + (rb == 10 ? (RT)1 : (RT)0);
@@ -712,14 +745,39 @@ solve_body(const DevParams& P, const int B,
       for (int l2 = lo; l2 < hi; ++l2) acc = fma(Cb - tb[l2], src[l2], acc);
       return acc;
     };
+    auto scan2 = [&](const bool prefix, const int rb0, const RT* src0, const int rb1, const RT* src1, RT& acc0, RT& acc1) {
+      const RT* tb0 = &sm.CT[rb0][0];
+      const RT* tb1 = &sm.CT[rb1][0];
+      const RT Cb0 = tb0[j] + (rb0 == 10 ? (RT)1 : (RT)0), Cb1 = tb1[j] + (rb1 == 10 ? (RT)1 : (RT)0);
+      acc0 = 0; acc1 = 0;
+      const int lo = prefix ? 0 : (wj0 & ~(SU - 1)), hi = prefix ? wj1 + 1 : H;       // (H is even: a pair of steps never leaves the horizon)
+#pragma unroll 1
+      for (int l2 = lo; l2 < hi; l2 += SU) {
+        RT t0[SU], s0[SU], t1[SU], s1[SU];
+#pragma unroll
+        for (int q = 0; q < SU; ++q) { t0[q] = tb0[l2 + q]; s0[q] = src0[l2 + q]; t1[q] = tb1[l2 + q]; s1[q] = src1[l2 + q]; }
+        BMPC_SCHED_BARRIER();
+#pragma unroll
+        for (int q = 0; q < SU; ++q) {
+          const bool on = prefix ? (l2 + q <= j) : (l2 + q >= j);
+          acc0 = fma(on ? Cb0 - t0[q] : (RT)0, s0[q], acc0);
+          acc1 = fma(on ? Cb1 - t1[q] : (RT)0, s1[q], acc1);
+        }
+      }
+    };
     const int sidx = c < 3 ? (hf == 0 ? a : 6 + a) : (hf == 0 ? 3 + a : 9 + a);
     RT ev = sm.err0[j][sidx];
     if (have_b) {                               // (uniform)
       const RT* src0 = c < 3 ? &sm.u.itv.yw[hf == 0 ? 0 : a][0] : &sm.u.itv.bwT[3 + a][0];
       const int rb0 = c < 3 ? (hf == 0 ? 3 * a : 10) : (hf == 0 ? 9 : 10);
-      const RT acc0 = scan(rb0, src0, 0, j + 1);
-      RT acc1 = 0;
-      if (c < 3) acc1 = scan(3 * a + (hf == 0 ? 1 : 2), &sm.u.itv.yw[hf == 0 ? 1 : 2][0], 0, j + 1);
+      RT acc0, acc1 = 0;
+      if constexpr (FUSED) {
+        scan2(true, rb0, src0, c < 3 ? 3 * a + (hf == 0 ? 1 : 2) : rb0, c < 3 ? &sm.u.itv.yw[hf == 0 ? 1 : 2][0] : src0, acc0, acc1);
+        acc1 = c < 3 ? acc1 : (RT)0;
+      } else {
+        acc0 = scan(rb0, src0, 0, j + 1);
+        if (c < 3) acc1 = scan(3 * a + (hf == 0 ? 1 : 2), &sm.u.itv.yw[hf == 0 ? 1 : 2][0], 0, j + 1);
+      }
       const RT got = pair_swap(acc1);           // (lane 0 of a torque row receives the b = 2 term)
       const RT scale = c < 3 ? (hf == 0 ? dt : (RT)1) : (hf == 0 ? kp : kvv);
       ev = fma(scale, c < 3 && hf == 0 ? acc0 + (acc1 + got) : acc0, ev);
@@ -731,9 +789,14 @@ solve_body(const DevParams& P, const int B,
       // (tab[i] - C_j = -(C_j - tab[i]): the sign goes into the scale of the table-driven kinds)
       const RT* src0 = &sm.u.itv.qvT[c < 3 ? (hf == 0 ? 0 : 6 + a) : (hf == 0 ? 3 + a : 9 + a)][0];
       const int rb0 = c < 3 ? (hf == 0 ? a : 10) : (hf == 0 ? 9 : 10);
-      const RT acc0 = scan(rb0, src0, j, H);
-      RT acc1 = 0;
-      if (c < 3) acc1 = scan(a + (hf == 0 ? 3 : 6), &sm.u.itv.qvT[hf == 0 ? 1 : 2][0], j, H);
+      RT acc0, acc1 = 0;
+      if constexpr (FUSED) {
+        scan2(false, rb0, src0, c < 3 ? a + (hf == 0 ? 3 : 6) : rb0, c < 3 ? &sm.u.itv.qvT[hf == 0 ? 1 : 2][0] : src0, acc0, acc1);
+        acc1 = c < 3 ? acc1 : (RT)0;
+      } else {
+        acc0 = scan(rb0, src0, j, H);
+        if (c < 3) acc1 = scan(a + (hf == 0 ? 3 : 6), &sm.u.itv.qvT[hf == 0 ? 1 : 2][0], j, H);
+      }
       part = c < 3 ? (hf == 0 ? -dt * (acc0 + acc1) : acc0 - dt * acc1) : (hf == 0 ? -kp * acc0 : kvv * acc0);
     }
     part += pair_swap(part);                   // both lanes of the pair: the same sum (a + b == b + a)
@@ -749,7 +812,6 @@ solve_body(const DevParams& P, const int B,
   // steps j2 = jb + jj of this lane's column half, laid out [b][jj]:
   // torque lane (j,a): Gt[(j,a)][(j2,b)] at b HH + jj ; force lane (j,3+a): Gt[(j,3+a)][(j2,3+a)] at a HH + jj, zeros elsewhere
   float Grow[GH];
-  float gdiag = 0.f;                           // Gt[row][row] (for the Jacobi scaling of Gt + F); both lanes of the pair
 #pragma unroll
   for (int q = 0; q < GH; ++q) Grow[q] = 0.f;
   // The torque block is a Gram matrix -- the dense horizon-block GEMM inside the condensed Hessian -- and is formed on the MATRIX
@@ -855,13 +917,12 @@ solve_body(const DevParams& P, const int B,
         for (int b = 0; b < 3; ++b) {
           const float gv = grow[3 * jj + b];
           Grow[b * HH + jj] = gv;
-          if (j2 == j && b == a) gdiag = gv;
           if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + b] = (double)gv;     // view of the row (tests)
         }
       }
     } else {
       const int a = c - 3;
-      const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
+      const RT kp = (RT)P.kpm, kvv = (RT)P.kvm;
 #pragma unroll
       for (int jj = 0; jj < HH; ++jj) {
         const int j2 = jb + jj;
@@ -872,12 +933,11 @@ solve_body(const DevParams& P, const int B,
         const RT gval = 2 * ((RT)P.Q[3 + a] * kp * kp * (RT)s2 + (RT)P.Q[9 + a] * kvv * kvv * (RT)n);
 #pragma unroll
         for (int a2 = 0; a2 < 3; ++a2) Grow[a2 * HH + jj] = (a2 == a) ? (float)gval : 0.f;
-        if (j2 == j) gdiag = (float)gval;
         if (dbg.Gt && real) dbg.Gt[((size_t)inst * NW + row) * NW + 6 * j2 + 3 + a] = gval;
       }
     }
   }
-  gdiag += pair_swap(gdiag);                   // one lane of the pair holds it, the other 0
+  // (gdiag itself is not kept: factor() picks Gt[row][row] out of the row half again -- one register less across the loop)
   sync_workgroup();                            // (the accumulator tiles share their LDS with the exchange vectors of the gradient)
   // qt = 2 Gam_t' Q (s - x_ref): the exact gradient at u = 0
   const RT qt = gradient_exact(false);
@@ -931,9 +991,13 @@ solve_body(const DevParams& P, const int B,
   constexpr float PIV_REG = 3.0e-5f;
   auto factor = [&]() {
     if constexpr (PROF) t_mark = clock64();
+#ifdef BMPC_PROF_BLOCKS
+    if constexpr (PROF) t_mark2 = t_mark;
+#endif
     // 6x6 block algebra in f64 (blocks mix penalties over ~6 decades); results stored f32.
     if (valid) sm.rvg[j][f][c] = rvg;
     sync_workgroup();
+    BMPC_BSTAMP(0)
     // factor-only data is rebuilt here from LDS and from an opaque copy of the component index, so that
     // none of it is hoisted out of the iteration loop (= holds registers during the iterations)
     int co = c, jo = j;
@@ -951,25 +1015,23 @@ solve_body(const DevParams& P, const int B,
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
       for (int a = 0; a < 3; ++a) rf[ft][a] = (float)sm.rr[j][ft][a];
-    double Tm[6][6];                           // T = [[I, 0], [[dr]x, I]]: (f2, m2) = -T (phi, nu) spans null(W)
-    {
-      const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
+    // T = [[I, 0], [S, I]], S = [dr]x: (f2, m2) = -T (phi, nu) spans null(W).  What a lane needs of it (round 6: picked by the
+    // component index, where the first version selected rows and columns of the 6x6 tables with 0 / 1 masks -- 144 f64 FMAs per
+    // lane and factorisation that multiplied by zero):
+    //   Scol = S[:, c] for c < 3, else 0      (column c of T below the diagonal: T[:, c] = e_c + [0; Scol])
+    //   Srow = S[c - 3, :] for c >= 3, else 0 (row c of T left of the diagonal:  T[c, :] = e_c + [Srow, 0])
+    //   R0row = [r_0]x[c - 3, :] for c >= 3, else 0  (row c of W_0^-T = [[0, I], [I, [r_0]x]] right of its unit entry)
+    // (each formed where it is used, from the lever arms: held across the stages they would cost 36 registers)
+    auto skew_pick = [&](const double (&v)[3], const bool rows, const int base, double (&o)[3]) {
+      // rows: o = [v]x[co - base, :], else o = [v]x[:, co - base]; zeros if co - base is not 0, 1, 2
+      const double M[3][3] = {{0.0, -v[2], v[1]}, {v[2], 0.0, -v[0]}, {-v[1], v[0], 0.0}};
+      const int a = co - base;
 #pragma unroll
-      for (int p = 0; p < 6; ++p)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Tm[p][q] = (p == q) ? 1.0 : 0.0;
-      Tm[3][1] = -dr[2]; Tm[3][2] = dr[1];
-      Tm[4][0] = dr[2];  Tm[4][2] = -dr[0];
-      Tm[5][0] = -dr[1]; Tm[5][1] = dr[0];
-    }
-    double Tcol[6], Trow[6];                   // T[:, c] and T[c, :]
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-      double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 6; ++cc) { a1 = fma(mkd[cc], Tm[p][cc], a1); a2 = fma(mkd[cc], Tm[cc][p], a2); }
-      Tcol[p] = a1; Trow[p] = a2;
-    }
+      for (int q = 0; q < 3; ++q) {
+        const double e0 = rows ? M[0][q] : M[q][0], e1 = rows ? M[1][q] : M[q][1], e2 = rows ? M[2][q] : M[q][2];
+        o[q] = a == 0 ? e0 : (a == 1 ? e1 : (a == 2 ? e2 : 0.0));
+      }
+    };
     // D_f = 2R + A' diag(rv) A: row c of the own foot's block
     double m3[6];
     if (valid) {
@@ -993,65 +1055,64 @@ solve_body(const DevParams& P, const int B,
       for (int b = 0; b < 6; ++b) (f == 0 ? sm.u.fac.M0 : sm.u.fac.M1)[j][c][b] = m3[b];
     }
     sync_step();
+    BMPC_BSTAMP(1)
     // One 6x6 inverse per step instead of four.  With Y = [W_0^-1; 0] (so W Y = I) and P the D-orthogonal
     // projector I - N Ka^-1 N' D:   L = D^-1 W' F = P Y,   F = (W D^-1 W')^-1 = Y' D L.  In blocks, with
     // B = T' D1 T (Ka = D0 + B) and I - Ka^-1 D0 = Ka^-1 B (no cancellation):
     //   L_0 = Ka^-1 B W_0^-1,   L_1 = T Ka^-1 D0 W_0^-1,   F = (W_0^-T D0) L_0,
-    // W_0^-1 = [[0, I], [I, -[r_0]x]].   The two lanes of a row share the work: lane 0 the Ka chain
-    // (B, Ka^-1, L_0, F), lane 1 the D0 chain (Ka^-1 D0 W_0^-1, L_1, T Ka^-1).
-    const bool on0 = valid && hf == 0, on1 = valid && hf == 1;
-    double urow[6];                             // row c of U = W_0^-T D0
-    double ka[6];                               // row c of Ka^-1
-    if (on0) {
-      double yq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      row_times_mat6(Tcol, sm.u.fac.M1[j], yq);
-      double brow[6];                           // row c of B
+    // W_0^-1 = [[0, I], [I, -[r_0]x]].
+    // The two lanes of a row share every product by COLUMNS (round 6): lane hf forms the entries b = 3 hf .. 3 hf + 2 of row c
+    // of each of them -- until round 5 lane 0 ran the Ka chain (B, L_0, F) and lane 1 the D0 chain (L_1, T Ka^-1) under
+    // complementary exec masks, so a wave issued both chains with half its lanes idle.  The sums keep the order of the dense
+    // 6-term form (rows of zeros skipped: fma(0, x, s) = s), so the factors are the same to the bit.  (the 6x6 inverse and the
+    // two products Ka^-1 B / Ka^-1 D0, one per lane, stay whole rows: different operands, nothing to share)
+    const int b0 = 3 * hf;                       // first column of this lane's half
+    // entries b0 .. b0 + 2 of row q of a 6x6 block in LDS (8-byte aligned)
+    auto row3 = [&](const double (*M)[6], const int q, double (&o)[3]) {
+      o[0] = M[q][b0]; o[1] = M[q][b0 + 1]; o[2] = M[q][b0 + 2];
+    };
+    double urh[3];                              // row c of U = W_0^-T D0, own columns
+    {
+      double dc[3], d3[3], d4[3], d5[3], e0[3], e3[3], e4[3], e5[3], ep[3];
+      const int pu = co < 3 ? co + 3 : co - 3;  // the unit entry of row c of W_0^-T
+      row3(sm.u.fac.M1[j], co, dc); row3(sm.u.fac.M1[j], 3, d3); row3(sm.u.fac.M1[j], 4, d4); row3(sm.u.fac.M1[j], 5, d5);
+      row3(sm.u.fac.M0[j], co, e0); row3(sm.u.fac.M0[j], pu, ep);
+      row3(sm.u.fac.M0[j], 3, e3); row3(sm.u.fac.M0[j], 4, e4); row3(sm.u.fac.M0[j], 5, e5);
+      BMPC_SCHED_BARRIER();
+      const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
+      const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
+      double Scol[3], R0row[3];
+      skew_pick(dr, false, 0, Scol);
+      skew_pick(r0, true, 3, R0row);
+      double yqh[3], oth[3];                    // row c of T' D1: own columns, the other lane's
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        double s = 0.0;
+      for (int k = 0; k < 3; ++k) yqh[k] = fma(Scol[2], d5[k], fma(Scol[1], d4[k], fma(Scol[0], d3[k], dc[k])));
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s = fma(yq[q], Tm[q][b], s);
-        brow[b] = s;
-        sm.u.fac.Ka[j][c][b] = m3[b] + s;
+      for (int k = 0; k < 3; ++k) oth[k] = pair_swap(yqh[k]);
+      // row c of B = (T' D1) T: its columns 0..2 (lane 0) pick up the columns 3..5 of T' D1 through S = [dr]x, its columns 3..5
+      // (lane 1: dz = 0) do not.  S[q][k] for k = 0, 1, 2 written out (the zero of the diagonal skipped).
+      const double dz[3] = {hf == 0 ? dr[0] : 0.0, hf == 0 ? dr[1] : 0.0, hf == 0 ? dr[2] : 0.0};
+      double br[3];
+      br[0] = fma(oth[2], -dz[1], fma(oth[1], dz[2], yqh[0]));
+      br[1] = fma(oth[2], dz[0], fma(oth[0], -dz[2], yqh[1]));
+      br[2] = fma(oth[1], -dz[0], fma(oth[0], dz[1], yqh[2]));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sm.u.fac.Ka[j][c][b0 + k] = e0[k] + br[k];
+        sm.u.fac.M2[j][c][b0 + k] = br[k];
+        urh[k] = fma(R0row[2], e5[k], fma(R0row[1], e4[k], fma(R0row[0], e3[k], ep[k])));
       }
-      // U = W_0^-T D0 = [[0, I], [I, [r_0]x]] D0: rows 0..2 are rows 3..5 of D0, row 3+a is row a + ([r_0]x D0[3:6])_a
-      double wti[6];                            // row c of W_0^-T
-      {
-        const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
-        double Wt[6][6];
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-#pragma unroll
-          for (int q = 0; q < 6; ++q) Wt[p][q] = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { Wt[a][3 + a] = 1.0; Wt[3 + a][a] = 1.0; }
-        Wt[3][4] = -r0[2]; Wt[3][5] = r0[1];
-        Wt[4][3] = r0[2];  Wt[4][5] = -r0[0];
-        Wt[5][3] = -r0[1]; Wt[5][4] = r0[0];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          double a1 = 0.0;
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc) a1 = fma(mkd[cc], Wt[cc][q], a1);
-          wti[q] = a1;
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < 6; ++b) urow[b] = 0.0;
-      row_times_mat6(wti, sm.u.fac.M0[j], urow);
-#pragma unroll
-      for (int b = 0; b < 6; ++b) sm.u.fac.M2[j][c][b] = brow[b];
     }
     sync_step();                          // Ka, B published; D1 consumed
+    BMPC_BSTAMP(2)
+    double ka[6];                               // row c of Ka^-1
     inv6_row(sm.u.fac.Ka[j], co, ka);           // both lanes of the row, each for itself: no exchange
-    if (on0) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.u.fac.M1[j][c][b] = ka[b];     // the whole Ka^-1 is needed for T Ka^-1 below
-    }
+    for (int k = 0; k < 3; ++k) sm.u.fac.M1[j][c][b0 + k] = hf == 0 ? ka[k] : ka[3 + k];   // the whole Ka^-1 is needed for T Ka^-1 below
     double xk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane 0: row c of Ka^-1 B ; lane 1: row c of Ka^-1 D0
-    if (on0) row_times_mat6(ka, sm.u.fac.M2[j], xk);
-    if (on1) row_times_mat6(ka, sm.u.fac.M0[j], xk);
+    row_times_mat6(ka, hf == 0 ? sm.u.fac.M2[j] : sm.u.fac.M0[j], xk);
     sync_step();                          // B, D0 consumed; Ka^-1 published
+    BMPC_BSTAMP(3)
     if (valid) {
       const double r0[3] = {(double)rf[0][0], (double)rf[0][1], (double)rf[0][2]};
       // (v W_0^-1) for a row v = [p, q]: [q, p - q x r_0]
@@ -1072,24 +1133,60 @@ solve_body(const DevParams& P, const int B,
       }
     }
     sync_step();
-    double fv64[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // row c of F (lane 0)
-    if (on0) {
-      row_times_mat6(urow, sm.u.fac.M2[j], fv64);     // F = U L_0
+    BMPC_BSTAMP(4)
+    double fv64[6];                             // row c of F = U L_0 (both lanes)
+    {
+      double urow[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) sm.KG[0].d[j][c][b][0] = (float)ka[b];
-    }
-    if (on1) {
-      double sl[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      row_times_mat6(Trow, sm.u.fac.M0[j], sl);       // L_1 = T (Ka^-1 D0 W_0^-1)
-      row_times_mat6(Trow, sm.u.fac.M1[j], sk);       // T Ka^-1
+      for (int k = 0; k < 3; ++k) {
+        const double o = pair_swap(urh[k]);
+        urow[k] = hf == 0 ? urh[k] : o;
+        urow[3 + k] = hf == 0 ? o : urh[k];
+      }
+      double fvh[3];
+      {
+        double l0[6][3];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        sm.LG[1].d[j][c][b][0] = (float)sl[b];
-        // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
-        sm.KG[1].d[j][c][b][0] = (float)sk[b];
+        for (int q = 0; q < 6; ++q) row3(sm.u.fac.M2[j], q, l0[q]);
+        BMPC_SCHED_BARRIER();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) s = fma(urow[q], l0[q][k], s);
+          fvh[k] = s;
+        }
+      }
+      BMPC_SCHED_BARRIER();                     // (the two groups of loads one after the other: 36 + 48 registers in flight otherwise)
+      {
+        double m0[3][3], mc[3], k0[3][3], kc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { row3(sm.u.fac.M0[j], q, m0[q]); row3(sm.u.fac.M1[j], q, k0[q]); }
+        row3(sm.u.fac.M0[j], co, mc); row3(sm.u.fac.M1[j], co, kc);
+        BMPC_SCHED_BARRIER();
+        const double dr[3] = {(double)rf[0][0] - rf[1][0], (double)rf[0][1] - rf[1][1], (double)rf[0][2] - rf[1][2]};
+        double Srow[3];
+        skew_pick(dr, true, 3, Srow);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          // L_1 = T (Ka^-1 D0 W_0^-1), T Ka^-1: row c of T is e_c + [Srow, 0]
+          const double sl = fma(Srow[2], m0[2][k], fma(Srow[1], m0[1][k], Srow[0] * m0[0][k])) + mc[k];
+          const double sk = fma(Srow[2], k0[2][k], fma(Srow[1], k0[1][k], Srow[0] * k0[0][k])) + kc[k];
+          sm.LG[1].d[j][c][b0 + k][0] = (float)sl;
+          // N Ka^-1 N' with N_0 = I, N_1 = -T is applied as N (Ka^-1 (N' r)): keep rows of Ka^-1 and T Ka^-1
+          sm.KG[1].d[j][c][b0 + k][0] = (float)sk;
+          sm.KG[0].d[j][c][b0 + k][0] = (float)(hf == 0 ? ka[k] : ka[3 + k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double o = pair_swap(fvh[k]);
+        fv64[k] = hf == 0 ? fvh[k] : o;
+        fv64[3 + k] = hf == 0 ? o : fvh[k];
       }
     }
     sync_step();
+    BMPC_BSTAMP(5)
     if (valid) {                               // rows c of G_f Kn_f and G_f L_f (f32, from the stored f32 factors)
       float gr[6];                             // row c of G_f: mu-free table, -mu_f on the f_z entry of a friction row
 #pragma unroll
@@ -1106,22 +1203,29 @@ solve_body(const DevParams& P, const int B,
         sm.LG[f].d[j][c][i][1] = gl;
       }
     }
+    BMPC_BSTAMP(6)
     if constexpr (PROF) { const long long t = clock64(); t_blocks += t - t_mark; t_mark = t; }
     // K' row half = Gt row half + F row on the own step, scaled to unit diagonal (S K' S, S = diag(K')^-1/2:
     // every pivot of the sweep is then <= 1, which the pivot-row update below relies on).
     float fv[6];
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      fv[b] = (float)fv64[b];
-      const float o = pair_swap(fv[b]);
-      fv[b] = hf == 0 ? fv[b] : o;
-    }
+    for (int b = 0; b < 6; ++b) fv[b] = (float)fv64[b];     // (both lanes of the pair hold the whole row)
     {
       float fd = 0.f;
 #pragma unroll
       for (int b = 0; b < 6; ++b) fd = fmaf((float)mkd[b], fv[b], fd);
       // (the regularised repeat after a pivot breakdown, see below: K' + reg diag(K'), i.e. S K' S + reg I up to the factor
       //  1 + reg; reg = 0 otherwise)
+      // Gt[row][row]: in the half of the pair whose columns hold the own step (the other lane contributes 0)
+      float gdiag = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < HH; ++jj) {
+        const bool own = (jb + jj == jo);
+        const float g0 = Grow[jj], g1 = Grow[HH + jj], g2 = Grow[2 * HH + jj];
+        const int a3 = co < 3 ? co : co - 3;
+        gdiag = own ? (a3 == 0 ? g0 : (a3 == 1 ? g1 : g2)) : gdiag;
+      }
+      gdiag += pair_swap(gdiag);
       const float dg = gdiag + fd;
       if (sweep_reg > 0.f) {                     // (uniform)
 #pragma unroll
@@ -1304,12 +1408,19 @@ solve_body(const DevParams& P, const int B,
   // same gamma.  g' is kept from the iteration before the test only; a factorisation in between drops it.
   bool aa_have = false;
   // exact rebuild of the carried products: see the stopping test
+  // 10 since round 6 (20 before).  The carried gradient's increments use the f32 copy of the Gt row: a systematic error of
+  // ~6e-8 |Gt| times the distance travelled since the last rebuild, which the soft directions (curvature 2R) amplify.  With
+  // commanded angular rates (REF:64-69: Rot, I_w differ at every step, the torque block of Gt is full and carries the small yaw
+  // inertia into every axis) a rebuild every 20 iterations left the dense family at 1.1e-5 / 1.9e-5 of the optimum on 4096
+  // turning instances at h = 16 / 20 where the stage family -- exact gradient in every iteration -- ends at 8e-7 / 1.0e-6; every
+  // 10: 1.1e-6 / 1.6e-6, and the BASELINE shapes improve too (config 5 u0: 6.1e-6 -> 1.6e-6).  Every 5 changes nothing more.
+  // Costs one more rebuild per solve: +2.3 % at h = 10 before the rebuild's scans were fused (below: -1.6 %), +2.1 % at
+  // h = 16, +1.4 % at h = 20 (profiles/r06_drift_*.txt).
 #ifndef BMPC_REFRESH_ITERS
-#define BMPC_REFRESH_ITERS 20
+#define BMPC_REFRESH_ITERS 10
 #endif
   constexpr int REFRESH_ITERS = BMPC_REFRESH_ITERS;
   int last_exact = 0;                          // iteration at which gbl, axg were last rebuilt exactly (the start: exact)
-  bool exact_close = false;
   // a stopping test that finds a residual more than FAR times its tolerance away cannot be followed by a
   // successful one check_every iterations later (the tail contracts by ~6 per 5 iterations): the next one is skipped
   constexpr float FAR = 1.0e3f;
@@ -1317,10 +1428,18 @@ solve_body(const DevParams& P, const int B,
   while (next_adapt < 1) next_adapt += P.adapt_every;                          // the test runs after ++it
   int n_adapt = 0;                             // re-classifications taken (the two-rate schedule: DevParams::adapt_early)
   int prev_act = 0;                            // classes of this lane's rows at the previous re-classification (bit 0: box row, bit 1: general row)
-  float res_p = 0.f, res_s = 0.f;
+  // (the residuals of the last stopping test go to resid_out AT the test -- eight bytes, 8.5 times per solve -- instead of living
+  //  in two vector registers until the end of the kernel; an instance that never reaches a test reports zeros)
+  if (l == 0 && resid_out) { resid_out[2 * inst] = 0.f; resid_out[2 * inst + 1] = 0.f; }
 
   // exact axg, bwl, gbl from x (exchange through LDS); all threads call
   auto refresh = [&](const bool with_gradient) {
+    // (through opaque copies of the lane's indices, like gradient_exact: the addresses below are formed here, at a rebuild,
+    //  instead of being kept -- or spilled -- across the iterations)
+    int rw_ = row, f = hf_lane;
+    BMPC_OPAQUE(rw_);
+    BMPC_OPAQUE(f);
+    const int j = rw_ / 6, c = rw_ - 6 * j;
     if (valid) sm.u.itv.xs[j][f][c] = xo;
     sync_step();
     if (valid) {
@@ -1527,7 +1646,7 @@ solve_body(const DevParams& P, const int B,
     // (no iteration added on the standing and mixed batches), 15-150 x tighter where it does not.  (Not at h = 12: the
     // three reduction slots would cost that kernel its fourth instance per CU, like the extrapolation.)
     constexpr bool U0 = (H != 12);
-    constexpr float U0_TOL = 5.f;
+    // (U0_TOL = 5: DevParams::eps_u0, slow_tol_r2_u0)
     constexpr int AA_MAX_FACTOR = 8;             // an instance still re-classifying after that is cycling between active sets: no extrapolation
 #define AA_SLOT(x) (H == 12 ? 0 : (x))
     const bool aa_keep = AA && P.accel != 0 && (it + 2 == next_check);           // the iteration before a stopping test
@@ -1627,7 +1746,7 @@ solve_body(const DevParams& P, const int B,
         BMPC_FENCE();
         rp = fmaxf(fabsf((float)st_pb), fabsf((float)st_pg));
         {                                       // pull of the inactive rows (see the stopping test)
-          const bool actb = (zb <= (RT)lb || zb >= (RT)ub) && yb != (RT)0;
+          const bool actb = (zb <= widen(lb) || zb >= widen(ub)) && yb != (RT)0;     // (widen: no f64 copy of the bounds held across the loop)
           const bool actg = (zg >= (RT)0) && yg != (RT)0;
           slw = fmaxf((actb || eqb) ? 0.f : rvb * fabsf((float)st_pb), actg ? 0.f : rvg * fabsf((float)st_pg));
         }
@@ -1659,15 +1778,18 @@ solve_body(const DevParams& P, const int B,
     // its word and moves by kappa_confirm (>= the length of a ladder: straight to its limit).  Not earlier: the classes of the first
     // iterations are wrong for a fifth of the rows, and a row sent to a limit on their word has to walk all the way back.
     auto reclassify = [&](float& nb, float& ng, int& act, const bool scheduled) {
-      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
-      const bool actb = (zb <= (RT)lb || zb >= (RT)ub) && yb != (RT)0;
+      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? P.kappa_sqrt : P.kappa_qrt);
+      const bool actb = (zb <= widen(lb) || zb >= widen(ub)) && yb != (RT)0;     // (widen: no f64 copy of the bounds held across the loop)
       const bool actg = (zg >= (RT)0) && yg != (RT)0;
       act = (actb ? 1 : 0) | (actg ? 2 : 0);
       const bool confirm = scheduled && P.kappa_confirm > 0.f && n_adapt >= P.confirm_from && n_adapt > 0 && nfac <= 10;   // (n_adapt: before this one)
       const int same = confirm ? ~(act ^ prev_act) : 0;
       const float kapb = (same & 1) ? P.kappa_confirm : kap, kapg = (same & 2) ? P.kappa_confirm : kap;
       // active rows move up by kappa towards their class ceiling, inactive ones down towards rho_lo
-      const float hib = c < 3 ? P.rho_hi_f : P.rho_hi_m, hig = c < 4 ? P.rho_hi_f : P.rho_hi_m;
+      int cq = row;                              // (opaque: the two class ceilings are picked here, six times per solve, instead of
+      BMPC_OPAQUE(cq);                           //  living in registers -- or in scratch -- across the iterations)
+      cq = cq % 6;
+      const float hib = cq < 3 ? P.rho_hi_f : P.rho_hi_m, hig = cq < 4 ? P.rho_hi_f : P.rho_hi_m;
       nb = eqb ? P.rho_eq : (actb ? fminf(rvb * kapb, hib) : fmaxf(rvb / kapb, P.rho_lo));
       ng = actg ? fminf(rvg * kapg, hig) : fmaxf(rvg / kapg, P.rho_lo);
     };
@@ -1690,7 +1812,7 @@ solve_body(const DevParams& P, const int B,
     // (1e-5 until round 4: the bound IS the accuracy this test enforces, and single instances of a batch sat right at it --
     //  1.0e-5 on 1 of 8192 standing instances, 3.5e-6 .. 5.6e-6 on the other shapes; at 1e-6 the batch maxima are 4e-7 ..
     //  2.6e-6 on both families for +0.0 .. 0.14 iterations: rows at the floor still pass it by two decades)
-    constexpr float SLOW_TOL = 1.0e-6f;
+    // (SLOW_TOL = 1e-6: DevParams::slow_tol_r2 = SLOW_TOL 2 R_min, formed on the host)
     constexpr float AA_GAMMA_MAX = 100.f;       // a secant step beyond the one of a 0.99 contraction is not trusted
     bool force_adapt = false;
     float flips = 0.f;                          // rows of the instance that changed class since the previous re-classification
@@ -1716,18 +1838,17 @@ solve_body(const DevParams& P, const int B,
       ++n_red;
       if constexpr (PROF) t_red += clock64() - t_r0;
       if (check_now) {
-        res_p = v5[0];
-        res_s = v5[1];
+        if (l == 0 && resid_out) { resid_out[2 * inst] = v5[0]; resid_out[2 * inst + 1] = v5[1]; }
         const float tol_p = P.eps_pri * fmaxf(1.f, v5[2]), tol_s = P.eps_dua * fmaxf(1.f, v5[3]);
         const bool bad = !(v5[0] == v5[0]) || !(v5[1] == v5[1]) || !(v5[3] < 3.0e38f);
         const float n0 = fmaxf(1.f, u0v[1]);
-        const bool small = v5[0] <= tol_p && v5[1] <= tol_s && u0v[0] <= U0_TOL * fmaxf(P.eps_pri, P.eps_dua) * n0;
+        const bool small = v5[0] <= tol_p && v5[1] <= tol_s && u0v[0] <= P.eps_u0 * n0;
         const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
         // The third test can only be answered by a re-classification (the lagging row's penalty comes down); an instance
         // that may not re-classify any more -- budget of factorisations spent, or adaptation switched off -- is taken as
         // it is rather than held back until the iteration cap.
         const bool can_adapt = nfac <= P.max_refactor && P.adapt_every > 0;
-        const bool slow_ok = !(v5[5] > SLOW_TOL * P.r2min * fmaxf(1.f, v5[3]) || u0v[2] > U0_TOL * SLOW_TOL * P.r2min * n0) || !can_adapt;
+        const bool slow_ok = !(v5[5] > P.slow_tol_r2 * fmaxf(1.f, v5[3]) || u0v[2] > P.slow_tol_r2_u0 * n0) || !can_adapt;
         // The exact rebuild of the carried products.  Their f32 increments drift by ~1e-7 of the distance travelled, and a
         // correction of that size moves the soft directions (curvature 2R against 1e2) by ~1e-5: it has to come while the
         // iteration is still further away than that, or the tail pays for it.  So the first stopping test that finds the
@@ -1744,15 +1865,8 @@ solve_body(const DevParams& P, const int B,
         //  1 in 10^4 a decade away from the reference's weights -- otherwise never comes near, drifts, and then cycles for good:
         //  1 of 16384 standing instances at Q x 10 ran into the iteration cap that way, 505 iterations with this)
         constexpr int FAR_REFRESH = 100;
-#ifndef BMPC_NEAR2
-#define BMPC_NEAR2 0.f
-#endif
-        constexpr float NEAR2 = BMPC_NEAR2;
-        const bool close = NEAR2 > 0.f && !(v5[0] > NEAR2 * tol_p || v5[1] > NEAR2 * tol_s);
-        if (!close) exact_close = false;
-        const bool rebuild = (nearby && age >= REFRESH_ITERS) || age >= FAR_REFRESH || (close && !exact_close && age > 0);
-        const bool done = small && slow_ok && age <= REFRESH_ITERS + 2 * check_every && (NEAR2 == 0.f || exact_close);
-        if (close && rebuild) exact_close = true;
+        const bool rebuild = (nearby && age >= REFRESH_ITERS) || age >= FAR_REFRESH;
+        const bool done = small && slow_ok && age <= REFRESH_ITERS + 2 * check_every;
         force_adapt = small && !slow_ok && !bad && it < P.max_iter;
         next_check += far ? 2 * check_every : check_every;
         // (on the way out only the net wrench is needed, for the states: the iterate is what it is)
@@ -1800,7 +1914,8 @@ solve_body(const DevParams& P, const int B,
       ++n_adapt;
       int period = P.adapt_every;
       if (P.adapt_late > 0 && n_adapt >= P.adapt_early)
-        period = (P.adapt_busy > 0 && flips > (float)P.adapt_flips) ? P.adapt_busy : P.adapt_late;
+        period = (P.adapt_busy > 0 && (int)flips > P.adapt_flips) ? P.adapt_busy : P.adapt_late;     // (flips: a small whole number; compared as an integer,
+                                                                                                       //  or (float)adapt_flips lives in a VECTOR register across the loop)
       next_adapt += period;
     }
     BMPC_STAMP(6)
@@ -1822,7 +1937,9 @@ solve_body(const DevParams& P, const int B,
   static_assert(sizeof(sm.LG) >= 25 * H * sizeof(float), "output staging does not fit the factor blocks");
   const bool want_states = states || warm.states64;
   if (real) {
-    const int pos = c < 3 ? 3 * f + c : 6 + 3 * f + (c - 3);       // [f1 f2 m1 m2]
+    int fo = f;                                  // (opaque: 3 f is formed here, not kept from the set-up until the end of the kernel)
+    BMPC_OPAQUE(fo);
+    const int pos = c < 3 ? 3 * fo + c : 6 + 3 * fo + (c - 3);     // [f1 f2 m1 m2]
     ost[j * 12 + pos] = (float)xo;
   }
   if (want_states) {
@@ -1851,7 +1968,7 @@ solve_body(const DevParams& P, const int B,
       } else {
         const int a = c - 3;
         RT p = hf == 0 ? sm.err0[i][3 + a] + (RT)sm.xrf[i][3 + a] : sm.err0[i][9 + a] + (RT)sm.xrf[i][9 + a];
-        const RT kp = dt * dt / (RT)P.m, kvv = dt / (RT)P.m;
+        const RT kp = (RT)P.kpm, kvv = (RT)P.kvm;
 #pragma unroll 1
         for (int j2 = 0; j2 <= i; ++j2) {
           const RT fa = sm.u.itv.bwT[3 + a][j2];
@@ -1894,7 +2011,6 @@ solve_body(const DevParams& P, const int B,
     if (iters_out) iters_out[inst] = it;
     if (status_out) status_out[inst] = status;
     if (nfactor_out) nfactor_out[inst] = nfac;
-    if (resid_out) { resid_out[2 * inst] = res_p; resid_out[2 * inst + 1] = res_s; }
   }
 }
 

@@ -1405,7 +1405,7 @@ stage_body(const DevParams& P, const int B,
     //  `scheduled`: a re-classification of the schedule (not the one the third stopping test forces): from number confirm_from + 1
     //  on a row found in the same class as at the previous one moves by kappa_confirm -- bmpc_kernels.hip.  act2: the two classes.)
     auto reclassify_v = [&](int s, RT zbv, RT ybv, RT zgv, RT ygv, float& nb, float& ng, int& act2, const bool scheduled) __attribute__((always_inline)) {
-      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? sqrtf(P.kappa) : sqrtf(sqrtf(P.kappa)));
+      const float kap = nfac <= 10 ? P.kappa : (nfac <= 16 ? P.kappa_sqrt : P.kappa_qrt);
       const bool actb = (zbv <= (RT)lb[s] || zbv >= (RT)ub[s]) && ybv != (RT)0;
       const bool actg = (zgv >= (RT)0) && ygv != (RT)0;
       act2 = (actb ? 1 : 0) | (actg ? 2 : 0);
@@ -1634,11 +1634,11 @@ stage_body(const DevParams& P, const int B,
         //  bmpc_kernels.hip)
         constexpr float U0_TOL = 5.f;
         const float n0 = fmaxf(1.f, v5[9]);
-        const bool small = v5[0] <= tol_p && v5[1] <= tol_s && v5[8] <= U0_TOL * fmaxf(P.eps_pri, P.eps_dua) * n0;
+        const bool small = v5[0] <= tol_p && v5[1] <= tol_s && v5[8] <= P.eps_u0 * n0;
         // (an instance that may not re-classify any more -- budget of factorisations spent, adaptation switched off -- is
         //  taken as it is: the third test can only be answered by a re-classification)
         const bool can_adapt = nfac <= P.max_refactor && P.adapt_every > 0;
-        const bool done = small && (!(v5[5] > SLOW_TOL * P.r2min * fmaxf(1.f, v5[3]) || v5[10] > U0_TOL * SLOW_TOL * P.r2min * n0) || !can_adapt);
+        const bool done = small && (!(v5[5] > P.slow_tol_r2 * fmaxf(1.f, v5[3]) || v5[10] > P.slow_tol_r2_u0 * n0) || !can_adapt);
         force_adapt = small && !done && !bad && it < P.max_iter;
         const bool far = v5[0] > FAR * tol_p || v5[1] > FAR * tol_s;
         next_check += far ? 2 * check_every : check_every;

@@ -147,6 +147,7 @@ static inline float wave_sum(float v) {
 #define BMPC_FENCE() do { } while (0)
 #define BMPC_OPAQUE(x) do { } while (0)
 #define BMPC_UNIFORM(x) (x)
+#define BMPC_UNIFORM_INT(x) (x)
 #define BMPC_SCHED_BARRIER() do { } while (0)
 
 static float g_bc[1024];
@@ -272,6 +273,8 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.lt = p->lt - 0.01; d.lh = p->lh - 0.02; d.alpha = p->alpha;
   for (int i = 0; i < 12; ++i) { d.x_cmd[i] = p->x_cmd[i]; d.Q[i] = p->Q[i]; d.R2[i] = 2.0 * p->R[i]; }
   for (int k = 0; k < 3; ++k) { d.sq_e[k] = std::sqrt(2.0 * p->Q[k]); d.sq_w[k] = p->dt * std::sqrt(2.0 * p->Q[6 + k]); }
+  d.kpm = p->dt * p->dt / p->m;
+  d.kvm = p->dt / p->m;
   {
     double rmin = p->R[0];
     for (int i = 1; i < 12; ++i) rmin = std::fmin(rmin, p->R[i]);
@@ -285,6 +288,14 @@ extern "C" int bmpc_emu_solve(const bmpc_params* p, int B, const float* x_fb, co
   d.rho = (float)p->rho; d.rho_eq = (float)(p->rho * p->rho_eq_scale); d.rho_lo = (float)p->rho_lo;
   d.rho_hi_f = (float)p->rho_hi_f; d.rho_hi_m = (float)p->rho_hi_m;
   d.eps_pri = (float)p->eps_pri; d.eps_dua = (float)p->eps_dua; d.kappa = (float)p->kappa;
+  {                                           // (f32 products exactly as the kernels used to form them: SLOW_TOL = 1e-6, U0_TOL = 5)
+    const float slow_tol = 1.0e-6f, u0_tol = 5.f;
+    d.kappa_sqrt = std::sqrt(d.kappa);
+    d.kappa_qrt = std::sqrt(std::sqrt(d.kappa));
+    d.slow_tol_r2 = slow_tol * d.r2min;
+    d.slow_tol_r2_u0 = u0_tol * slow_tol * d.r2min;
+    d.eps_u0 = u0_tol * std::fmax(d.eps_pri, d.eps_dua);
+  }
   bmpc::DebugOut dbg = {dbg_x_ref, dbg_foot_ref, dbg_Gt, dbg_qt, nullptr, assemble_only};
   bmpc::WarmArgs warm = {warm_buf, warm_load, warm_store, warm_shift, (float)warm_theta, p->warm_adapt_start};
   if (const char* e = std::getenv("BMPC_EMU_POISON")) g_poison = std::atoi(e);

@@ -1406,8 +1406,10 @@ _AT_SCALE = [("config2_standing_h10", 8192, 10, "standing", 31, {}),
              ("turning_mu_h20", 4096, 20, "walking", 63, dict(vx_cmd=True, per_step_mu=True, turn=True))]
 
 
-# regression bounds (all controls, u0) of the batches that do not sit at the common 1e-5 / 2e-5
-_AT_SCALE_BOUNDS = {"turning_trot_h16": (3e-5, 5e-5), "turning_mu_h20": (3e-5, 5e-5)}
+# regression bounds (all controls, u0) of batches that do not sit at the common 1e-5 / 2e-5: none.  (The turning batches did not
+# when they were added: the dense family ended at 1.1e-5 / 1.9e-5 on them -- the drift of its carried gradient between exact rebuilds,
+# REFRESH_ITERS in bmpc_kernels.hip; rebuilt every 10 iterations instead of 20 it ends at 1.1e-6 / 1.6e-6 like the stage family.)
+_AT_SCALE_BOUNDS = {}
 
 
 @pytest.mark.parametrize("label,B,h,gait,seed,kw", _AT_SCALE, ids=[a[0] for a in _AT_SCALE])
@@ -1448,7 +1450,8 @@ def test_parity_against_the_oracle_at_scale(label, B, h, gait, seed, kw):
         assert e.max() <= util.REL_TOL and e0.max() <= util.REL_TOL
         # regression bounds well inside the tolerance (measured on MI355X: profiles/r04_parity_at_scale.txt; the turning batches of
         # round 6: profiles/r06_parity_at_scale.txt)
-        b_all, b_u0 = _AT_SCALE_BOUNDS.get(label, (1e-5, 2e-5))
+        b_all, b_u0 = _AT_SCALE_BOUNDS.get(label, (5e-6, 1e-5))        # (round 6: measured maxima 2.0e-6 / 2.8e-6 over the seven shapes, both families;
+                                                                       #  1e-5 / 2e-5 until round 5)
         assert e.max() <= b_all and e0.max() <= b_u0, (e.max(), e0.max())
 
 

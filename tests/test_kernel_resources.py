@@ -35,18 +35,16 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
                                      if k != "offset" and k != "size"}
     assert sorted(seen) == [8, 10, 12, 14, 16, 18, 20], seen
     for h, meta in seen.items():
-        # everything in registers up to h = 14; the long dense horizons (48 .. 60 floats of a row half next to the f64 state)
-        # are allowed spilled registers -- set-up values stored ONCE and reloaded at the stopping tests (the exact rebuild of
-        # the gradient in state space, round 4: ~25 transient registers at the point where the whole loop state is live)
-        # and at the outputs; test_no_scratch_access_in_the_hot_loops below holds that none is touched per iteration
-        # (measured, round 5: 13 at h = 18, 34 at h = 20 -- 9 / 17 in round 4; the count moves by +-25 with edits that do not touch the
-        #  loop at all (removing the states output of the epilogue: 56; one reduction value less: 60), i.e. it is the allocator's
-        #  choice of what to park where among set-up values, not a measure of the loop's pressure: config 5 runs at 6.10 ms per
-        #  8192 with 34 as it did with 17.  The bound is the measured value + 2; what must not happen -- a scratch access per
-        #  iteration or per sweep step -- is what test_no_scratch_access_in_the_hot_loops holds.)
-        assert int(meta["vgpr_spill_count"]) <= {8: 0, 10: 0, 12: 0, 14: 0, 16: 0, 18: 15, 20: 36}[h], (h, meta)
-        assert int(meta["private_segment_fixed_size"]) <= 160, (h, meta)      # (where nothing spills no scratch instruction exists:
-                                                                               #  test_no_scratch_access_in_the_hot_loops counts them)
+        # Round 6: NOTHING spills up to h = 18, and h = 20 keeps 4 dwords (a set-up index, an LDS address, one f64 -- reloaded at
+        # stopping tests / on the way out; test_no_scratch_access_in_the_hot_loops) where round 5 had 13 / 34 spilled registers
+        # at h = 18 / 20 and 132 bytes of scratch.  What moved it was not the allocator's mood but what the loop keeps alive:
+        # uniform f32 products of the stopping test and the re-classification formed on the host (gfx950 has no scalar float
+        # unit: formed in the kernel they are loop invariants in VECTOR registers), f64 copies of the bounds widened at their
+        # use, the lane's indices formed again from the row where a rebuild needs them, the residual norms stored at the test
+        # instead of carried to the end of the kernel, Gt[row][row] picked out of the row half by factor().  The bounds are
+        # the measured values: they go down with the code, not up.
+        assert int(meta["vgpr_spill_count"]) <= {8: 0, 10: 0, 12: 0, 14: 0, 16: 0, 18: 0, 20: 4}[h], (h, meta)
+        assert int(meta["private_segment_fixed_size"]) <= (20 if h == 20 else 0), (h, meta)
         assert int(meta["vgpr_count"]) + meta["agpr_count"] <= 256, (h, meta)      # two waves per SIMD
         lds = int(meta["group_segment_fixed_size"])
         waves = (12 * h + 63) // 64 if h % 5 else 2 * (h // 5) * 64 // 64
@@ -65,16 +63,15 @@ def test_no_spills_and_two_waves_per_simd(isa_text):
         steps = 5 * n_p * n_w
         assert lds <= 2000 * steps + 6000 * n_w, (n_p, n_w, lds)    # ~2 KB per step + the block-algebra scratch of one pass
         assert 160 * 1024 // lds >= 2, (n_p, n_w, lds)              # at least two instances per CU at h = 40
-        # (no variant spills -- except, since round 5, the five-steps-per-lane one (h = 21 .. 24, all 512 registers): 4 - 6 registers,
-        #  set-up values, 20 bytes of scratch, with the two-rate schedule's counters and the fp64 epilogue in the kernel)
-        assert int(meta["vgpr_spill_count"]) <= (8 if (n_p, n_w) == (5, 1) else 0), (n_p, n_w, meta)
-        assert int(meta["private_segment_fixed_size"]) <= (32 if (n_p, n_w) == (5, 1) else 0), (n_p, n_w, meta)
+        # (no variant spills a vector register -- round 5's five-steps-per-lane one (h = 21 .. 24, all 512 registers) kept 6 in
+        #  scratch: uniform f32 values of the stopping test, formed on the host since round 6)
+        assert int(meta["vgpr_spill_count"]) == 0 and int(meta["private_segment_fixed_size"]) == 0, (n_p, n_w, meta)
         # What the family costs in registers, stated as it is (the round-3 test asserted `vgpr_count <= 512`, the
         # hardware maximum): every variant needs MORE than 256 of the unified 512 registers (the count includes the AGPRs it
         # parks values in), i.e. one wave per SIMD, and keeps ~200 uniform values in lanes of VGPRs (SGPR spills: v_writelane /
         # v_readlane, no scratch).  These bounds are regression guards for DESIGN.md section 5b's numbers, not targets.
         assert 256 < int(meta["vgpr_count"]) <= 512, (n_p, n_w, meta)
-        assert int(meta["sgpr_spill_count"]) <= 256, (n_p, n_w, meta)      # (195 .. 249 in round 5; 174 .. 222 in round 4)
+        assert int(meta["sgpr_spill_count"]) <= 252, (n_p, n_w, meta)      # (193 .. 251 in round 6, 195 .. 249 in round 5; 174 .. 222 in round 4)
         # instances per CU: LDS admits 160 KB / lds, one wave per SIMD admits 4 / n_w -- the smaller one is what DESIGN.md quotes
         per_cu = min(160 * 1024 // lds, 4 // n_w)
         assert per_cu == {(2, 1): 4, (3, 1): 4, (4, 1): 4, (5, 1): 3, (3, 2): 2, (4, 2): 2}[(n_p, n_w)], (n_p, n_w, per_cu)
@@ -103,7 +100,7 @@ def test_hessian_block_gemm_runs_on_the_matrix_cores(isa_text):
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which(HIPCC)), reason="hipcc not available")
 def test_no_scratch_access_in_the_hot_loops(isa_text):
-    """Where a dense kernel spills (h >= 16), the spilled values are stored during the set-up and reloaded in code that
+    """Where a dense kernel spills (round 6: h = 20 only, 4 dwords), the spilled values are stored during the set-up and reloaded in code that
     runs at stopping tests / on the way out only: no scratch instruction sits in the body of the sweep loop or of the ADMM
     iteration.  Both hot bodies are recognisable in the ISA by their packed FMAs: the code between the first and the last
     `v_pk_fma_f32` of a kernel spans the sweep loop and the iteration's phases P0-P5 (mat-vec and gradient increment);
@@ -136,7 +133,7 @@ def test_no_scratch_access_in_the_hot_loops(isa_text):
         # the iteration phases: from the end of the sweep loop to the last packed FMA (the gradient increment of P5)
         loads = [x for x in body[b:pk[-1] + 1] if x.startswith("scratch_load")]
         assert len(loads) <= 2, (m.group(1), "scratch loads between the sweep and the end of the iteration phases", loads)
-        if int(m.group(1)) <= 16:               # nothing spills up to h = 16: no scratch instruction at all
+        if int(m.group(1)) <= 18:               # nothing spills up to h = 18: no scratch instruction at all
             assert not any(x.startswith("scratch_") for x in body), m.group(1)
     assert seen == 7
 

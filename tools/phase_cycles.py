@@ -30,6 +30,9 @@ print('B',B,'kernel ms',e0.elapsed_time(e1))
 print('cycles mean: setup %.0f blocks %.0f sweeps %.0f total %.0f | iters %.1f nfac %.2f'%tuple(pr[:,:6].mean(0)))
 it=pr[:,3]-pr[:,0]-pr[:,1]-pr[:,2]
 print('iteration cycles per iter %.0f ; blocks per factor %.0f ; sweep per factor %.0f'%((it/pr[:,4]).mean(),(pr[:,1]/pr[:,5]).mean(),(pr[:,2]/pr[:,5]).mean()))
+if '--blocks' in sys.argv:          # (a library built with -DBMPC_PROF_BLOCKS: the phase slots hold the stages of the block algebra)
+    print('block algebra, cycles per factorisation: ' + ' '.join('%s %.0f'%(n,v) for n,v in zip(['rvg+sync','D rows','Ka/B/U','inv6+KaB','w0','F/L1/TKa','G images'], (pr[:,8:15]/pr[:,5:6]).mean(0))))
+    sys.exit(0)
 print('iteration phases, cycles per iteration: ' + ' '.join('%s %.0f'%(n,v) for n,v in zip(['P0','P1','P2','P3','P4','P5','tail'], (pr[:,8:15]/pr[:,4:5]).mean(0))))
 nred=np.floor(pr[:,15]/1000); nreb=pr[:,15]-1000*nred
 print('tail per solve: %.0f cycles = reductions %.0f (%.1f of them, %.0f each) + rebuilds / last refresh %.0f (%.2f rebuilds) + rest %.0f'%(
