@@ -1,6 +1,6 @@
 """Convergence soaks (GPU box): how many instances of large random batches do not converge, and the worst iteration count.
 
-    python tools/soak.py shapes [--set base|long|stage|short] [--seeds LO HI]
+    python tools/soak.py shapes [--set base|turn|long|stage|short] [--seeds LO HI]
         random batches of the BASELINE config shapes over a range of seeds (base: the four shapes, 65536 / 16384 per seed;
         long: h = 16 / 20 variants; stage: six long-horizon shapes on the stage-structured kernels, 8192 per seed)
     python tools/soak.py params [--cases Q_x10,R_div100,...] [--rescue off|auto|on] [--paths 1,2] [--horizons 10,20] [--batch N]
@@ -26,6 +26,9 @@ SHAPE_SETS = {
              (20, "walking", dict(vx_cmd=True, per_step_mu=True))),
     "long": ((16, "walking", dict(vx_cmd=True)), (20, "walking", dict(vx_cmd=True, per_step_mu=True)),
              (16, "mixed", dict(vx_cmd=True)), (20, "standing", dict(per_step_mu=True))),
+    # round 6: commanded angular rates / attitude set-points / lateral commands (synth_batch turn=True)
+    "turn": ((10, "mixed", dict(vx_cmd=True, turn=True)), (10, "standing", dict(turn=True)), (16, "walking", dict(vx_cmd=True, turn=True)),
+             (20, "walking", dict(vx_cmd=True, per_step_mu=True, turn=True))),
     # odd and short horizons (stage-structured family; round 5)
     "short": ((1, "walking", dict(vx_cmd=True)), (2, "mixed", dict(vx_cmd=True)), (3, "walking", dict(vx_cmd=True, per_step_mu=True)),
               (5, "mixed", dict(vx_cmd=True)), (7, "walking", dict(vx_cmd=True, per_step_mu=True)), (9, "standing", {}),
