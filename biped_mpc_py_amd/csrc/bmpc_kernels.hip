@@ -1287,9 +1287,98 @@ solve_body(const DevParams& P, const int B,
     // Two pivots per barrier and LDS round trip instead of one; the update of the NEXT pair of pivot columns
     // is done first and published at once (into the other buffer), so that its round trip overlaps with the
     // rest of this step's updates.
+    constexpr int PVS = Dims<H>::PVS;            // floats per published column (two-half layout + dump slots)
+    // Up to h = 18 the sweep is unrolled over the HN / 2 steps of a column half and the register file does NOT rotate (round 6):
+    // column k sits in register k mod HN of the lanes of half k / HN for good, every register index below is static, and the
+    // half whose lanes publish is the only thing that changes from the first pass to the second.  The rotating form (below)
+    // keeps the code to three steps and pays for it per group of three: 6 DPP moves + ~24 register moves + the selects that
+    // go with them, ~10 of a step's ~98 instructions at h = 10 (88.6 now).  Measured (tools/ab.py, one box, interleaved):
+    // sweep 26.6 k -> 24.5 k cycles per factorisation at h = 10, kernel -2.3 % (configs 2, 4), -2.3 % at h = 16, -0.8 % at
+    // h = 20 -- where the unrolled form spills 12 registers instead of 4 and the rotating one stays.  Same arithmetic in the
+    // same order: iteration counts and results identical to the bit.
+#ifndef BMPC_STATIC_HN
+#define BMPC_STATIC_HN 54
+#endif
+    constexpr bool STATIC_SWEEP = HN <= BMPC_STATIC_HN;
+    if constexpr (STATIC_SWEEP) {
+      const int ps = slot<H>(row);              // the own row's entry in a published column
+      {
+        const int ws0 = hf == 0 ? ps : Dims<H>::VL + row;
+        sm.piv[0][ws0] = Vr[0].x;
+        sm.piv[0][PVS + ws0] = Vr[0].y;
+      }
+      int par = 0;
+#pragma unroll 1
+      for (int hh = 0; hh < 2; ++hh) {           // the column half that holds the pivots
+        const int wsh = hf == hh ? ps : Dims<H>::VL + row;              // publication slot while this half publishes (else: dump)
+        const int wso = hf == hh + 1 ? ps : Dims<H>::VL + row;          // ... and for the first pivots of the next half
+        const int kb = hh * HN;                   // first pivot of the half
+        const int pb0 = hh * HNP;                 // its slot
+#pragma unroll
+        for (int u = 0; u < HN; u += 2) {
+          const float* bA = sm.piv[par];                   // column k = kb + u
+          const float* bB = bA + PVS;                      // column k + 1
+          float* nA = sm.piv[par ^ 1];
+          par ^= 1;
+          const int un = u + 2 < HN ? (u >> 1) + 1 : 0;  // register pair of the next pivot columns (last step of a half: the other half's first)
+          sync_workgroup();
+          const float2 pk = *reinterpret_cast<const float2*>(&bA[pb0 + u]);      // V[k][k], V[k + 1][k]
+          const float p11 = bB[pb0 + u + 1];
+          const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
+          BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
+          const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
+          const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
+          qmax = fmaxf(qmax, fmaxf(q00, q11));             // (pivot check: see the rotating form)
+          qmin = fminf(qmin, fminf(q00, q11));
+          const bool is0 = (row == kb + u), is1 = (row == kb + u + 1);
+          float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
+          t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
+          t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
+          const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
+          // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the next pivot
+          // columns first: they are updated first and published at once, so that their round trip overlaps with the rest
+          constexpr int CH = HN <= 32 ? HN : 16;
+          static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
+          constexpr int NCH = (HN + CH - 1) / CH;
+          const int ch0 = (2 * un) / CH;                    // (static: the loops are unrolled)
+#pragma unroll
+          for (int cc = 0; cc < NCH; ++cc) {
+            const int ci = cc == 0 ? ch0 : (cc <= ch0 ? cc - 1 : cc);       // chunk ch0 first, the others in order
+            const int c0i = ci * CH;
+            const int c1i = c0i + CH < HN ? c0i + CH : HN;
+            f2 pa[CH / 2], pb[CH / 2];
+#pragma unroll
+            for (int q = c0i; q < c1i; q += 4) {
+              if (q + 4 <= c1i) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
+                const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
+                pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
+                pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
+              } else {
+                const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
+                const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
+                pa[(q - c0i) / 2] = f2{a2.x, a2.y};
+                pb[(q - c0i) / 2] = f2{b2.x, b2.y};
+              }
+            }
+            if (cc == 0) {
+              Vr[un] = __builtin_elementwise_fma(m1, pb[un - c0i / 2], __builtin_elementwise_fma(m0, pa[un - c0i / 2], Vr[un]));
+              const int wn = u + 2 < HN ? wsh : wso;         // (after the very last step: columns nobody reads)
+              nA[wn] = Vr[un].x;
+              nA[PVS + wn] = Vr[un].y;
+            }
+#pragma unroll
+            for (int r = c0i / 2; r < c1i / 2; ++r)
+              if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
+            if (cc + 1 < NCH) BMPC_FENCE();
+          }
+          if (hf == hh) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
+        }
+        BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
+      }
+    } else {
     constexpr int U = 6;
     static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
-    constexpr int PVS = Dims<H>::PVS;            // floats per published column (two-half layout + dump slots)
     int pos = row;                              // rotated index of the own row (group 0)
     int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
     sm.piv[0][ws] = Vr[0].x;
@@ -1373,6 +1462,7 @@ solve_body(const DevParams& P, const int B,
       pos = posn;
       ws = wsn;
       BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
+    }
     }
     piv_bad = !(qmax < 1.f / PIV_MIN) || !(qmin > 0.f);     // (an infinite reciprocal -- a zero determinant -- fails too)
     if constexpr (PROF) t_sweep += clock64() - t_mark;

@@ -1684,7 +1684,7 @@ stage_body(const DevParams& P, const int B,
       ++n_adapt;
       int period = P.adapt_every;
       if (P.adapt_late > 0 && n_adapt >= P.adapt_early)
-        period = (P.adapt_busy > 0 && flips > (float)P.adapt_flips) ? P.adapt_busy : P.adapt_late;
+        period = (P.adapt_busy > 0 && (int)flips > P.adapt_flips) ? P.adapt_busy : P.adapt_late;
       next_adapt += period;
     }
     BMPC_SSTAMP(5)
