@@ -147,12 +147,15 @@ typedef struct bmpc_params {
   int32_t adapt_busy;        /* ... but `adapt_busy` iterations after a (late) re-classification that still found more than `adapt_flips` of
                                 the instance's rows in another class than the one before: the instances that keep turning are the
                                 tail of a batch and are not made to wait.  0: always adapt_late.  Default at h <= 12: 10, 1.
-                                (Not on the kernels that carry no secant step -- dense h = 12, stage h = 22 / 24: always adapt_late.) */
+                                (Ignored -- always adapt_late -- by the kernels that do not count class changes: the dense h = 12
+                                kernel, whose reduction has no slot for it, and the five-steps-per-lane stage variant, h = 21 .. 24.) */
   int32_t adapt_flips;
   int32_t confirm_from;      /* confirmation: from re-classification number confirm_from + 1 on, a row found in the SAME class as at the
                                 previous re-classification moves by kappa_confirm instead of kappa (>= the length of a ladder: straight
                                 to its ceiling / floor) -- a row that turns late otherwise costs three more factorisations walking
-                                there.  Default at h <= 12: 3, 400; kappa_confirm = 0: off */
+                                there.  Default at h <= 12: 3, 400; kappa_confirm = 0: off.  (Ignored by the five-steps-per-lane
+                                stage variant, h = 21 .. 24 -- no register for the previous classes; the dense h = 12 kernel DOES
+                                confirm: it keeps the classes, it only does not count their changes.) */
   int32_t reserved0;
   double kappa_confirm;
   /* low-level control side of the loop (REF:29-32, 43): used by bmpc_low_level_control* / bmpc_foot_position_world* only */
