@@ -1275,10 +1275,8 @@ solve_body(const DevParams& P, const int B,
       }
     }
     float qmax = 0.f, qmin = 1.f;
-    // Symmetric sweep, TWO pivots per step, with a rotating register file: at group k0 register i of half hf
-    // holds column (k0 + hf HN + i) mod NW, so the pivot columns k, k + 1 are always one static register pair
-    // of the half-0 lanes.  Step S = {k, k + 1}, P = V[S, S]: the half-0 lanes publish their two entries of the
-    // pivot columns (= pivot rows, by symmetry), every lane fetches the 2 HN entries of its half, forms its
+    // Symmetric sweep, TWO pivots per step.  Step S = {k, k + 1}, P = V[S, S]: the lanes that hold the pivot columns
+    // publish their two entries of them (= pivot rows, by symmetry), every lane fetches the 2 HN entries of its half, forms its
     // T[r, :] = V[r, S] P^-1 and updates with TWO packed FMAs per register pair:  row -= T[r, 0] row_k +
     // T[r, 1] row_k+1; the pivot rows themselves use T[r, :] = e_r - P^-1[r, :], which turns them into
     // P^-1 V[S, :] (exact up to rounding because the scaled pivots are <= 1; no second multiply, and a row is
@@ -1377,92 +1375,95 @@ solve_body(const DevParams& P, const int B,
         BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
       }
     } else {
-    constexpr int U = 6;
-    static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
-    int pos = row;                              // rotated index of the own row (group 0)
-    int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
-    sm.piv[0][ws] = Vr[0].x;
-    sm.piv[0][PVS + ws] = Vr[0].y;
-    int par = 0;                                // buffer of the current step (a group has an odd number of steps)
+      // The rotating form (h = 20): groups of U = 6 pivots are unrolled; at group k0 register i of half hf holds column
+      // (k0 + hf HN + i) mod NW, so the pivot columns are always the first registers of the half-0 lanes, and the register file
+      // is rotated by U across the lane pair after every group.
+      constexpr int U = 6;
+      static_assert(NW % U == 0 && U % 2 == 0 && U + 2 <= HN, "sweep group must divide 6H and be even");
+      int pos = row;                              // rotated index of the own row (group 0)
+      int ws = hf == 0 ? slot<H>(pos) : Dims<H>::VL + row;
+      sm.piv[0][ws] = Vr[0].x;
+      sm.piv[0][PVS + ws] = Vr[0].y;
+      int par = 0;                                // buffer of the current step (a group has an odd number of steps)
 #pragma unroll 1
-    for (int k0 = 0; k0 < NW; k0 += U) {
-      const int ps = slot<H>(pos);
-      int posn = pos - U;                       // ... and in the next group
-      posn += (posn < 0) ? NW : 0;
-      const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
+      for (int k0 = 0; k0 < NW; k0 += U) {
+        const int ps = slot<H>(pos);
+        int posn = pos - U;                       // ... and in the next group
+        posn += (posn < 0) ? NW : 0;
+        const int wsn = hf == 0 ? slot<H>(posn) : Dims<H>::VL + row;
 #pragma unroll
-      for (int u = 0; u < U; u += 2) {
-        const float* bA = sm.piv[par];                   // column k
-        const float* bB = bA + PVS;                      // column k + 1
-        float* nA = sm.piv[par ^ 1];
-        par ^= 1;
-        const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
-        sync_workgroup();
-        const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
-        const float p11 = bB[u + 1];
-        const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
-        BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
-        const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
-        const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
-        // (pivot check, two instructions: the diagonal of P^-1 holds the reciprocals of the two pivots -- of the second one
-        //  and of the first one's Schur complement against it; both must be positive -- rounding can turn a lost pivot
-        //  negative -- and below 1 / PIV_MIN.  Every lane reads the same values.)
-        qmax = fmaxf(qmax, fmaxf(q00, q11));
-        qmin = fminf(qmin, fminf(q00, q11));
-        const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
-        float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
-        t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
-        t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
-        const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
-        // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the
-        // next pivot columns first
-        constexpr int CH = HN <= 32 ? HN : 16;
-        static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
+        for (int u = 0; u < U; u += 2) {
+          const float* bA = sm.piv[par];                   // column k
+          const float* bB = bA + PVS;                      // column k + 1
+          float* nA = sm.piv[par ^ 1];
+          par ^= 1;
+          const int un = (u >> 1) + 1;             // register pair of the next pivot columns (u + 2 == U: first of the next group)
+          sync_workgroup();
+          const float2 pk = *reinterpret_cast<const float2*>(&bA[u]);      // V[k][k], V[k + 1][k]
+          const float p11 = bB[u + 1];
+          const float c0 = bA[ps], c1 = bB[ps];            // V[r][k], V[r][k + 1]
+          BMPC_SCHED_BARRIER();                            // the step's scalar loads are in flight before anything is used
+          const float id = rcp_approx(pk.x * p11 - pk.y * pk.y);
+          const float q00 = p11 * id, q01 = -pk.y * id, q11 = pk.x * id;  // P^-1
+          // (pivot check, two instructions: the diagonal of P^-1 holds the reciprocals of the two pivots -- of the second one
+          //  and of the first one's Schur complement against it; both must be positive -- rounding can turn a lost pivot
+          //  negative -- and below 1 / PIV_MIN.  Every lane reads the same values.)
+          qmax = fmaxf(qmax, fmaxf(q00, q11));
+          qmin = fminf(qmin, fminf(q00, q11));
+          const bool is0 = (row == k0 + u), is1 = (row == k0 + u + 1);
+          float t0 = c0 * q00 + c1 * q01, t1 = c0 * q01 + c1 * q11;
+          t0 = is0 ? 1.f - q00 : (is1 ? -q01 : t0);
+          t1 = is0 ? -q01 : (is1 ? 1.f - q11 : t1);
+          const f2 m0 = {-t0, -t0}, m1 = {-t1, -t1};
+          // the pivot rows are fetched in chunks of at most CH entries each (registers), the chunk with the
+          // next pivot columns first
+          constexpr int CH = HN <= 32 ? HN : 16;
+          static_assert(CH % 4 == 0 || CH == HN, "chunk of whole float4s");
 #pragma unroll
-        for (int c0i = 0; c0i < HN; c0i += CH) {
-          const int c1i = c0i + CH < HN ? c0i + CH : HN;
-          f2 pa[CH / 2], pb[CH / 2];
+          for (int c0i = 0; c0i < HN; c0i += CH) {
+            const int c1i = c0i + CH < HN ? c0i + CH : HN;
+            f2 pa[CH / 2], pb[CH / 2];
 #pragma unroll
-          for (int q = c0i; q < c1i; q += 4) {
-            if (q + 4 <= c1i) {
-              const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
-              const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
-              pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
-              pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
-            } else {
-              const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
-              const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
-              pa[(q - c0i) / 2] = f2{a2.x, a2.y};
-              pb[(q - c0i) / 2] = f2{b2.x, b2.y};
+            for (int q = c0i; q < c1i; q += 4) {
+              if (q + 4 <= c1i) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&bA[hf * HNP + q]);
+                const float4 b4 = *reinterpret_cast<const float4*>(&bB[hf * HNP + q]);
+                pa[(q - c0i) / 2] = f2{a4.x, a4.y}; pa[(q - c0i) / 2 + 1] = f2{a4.z, a4.w};
+                pb[(q - c0i) / 2] = f2{b4.x, b4.y}; pb[(q - c0i) / 2 + 1] = f2{b4.z, b4.w};
+              } else {
+                const float2 a2 = *reinterpret_cast<const float2*>(&bA[hf * HNP + q]);
+                const float2 b2 = *reinterpret_cast<const float2*>(&bB[hf * HNP + q]);
+                pa[(q - c0i) / 2] = f2{a2.x, a2.y};
+                pb[(q - c0i) / 2] = f2{b2.x, b2.y};
+              }
             }
-          }
-          if (c0i == 0) {
-            static_assert(U / 2 + 1 <= CH / 2, "the next pivot pair lies in the first chunk");
-            Vr[un] = __builtin_elementwise_fma(m1, pb[un], __builtin_elementwise_fma(m0, pa[un], Vr[un]));
-            const int wn = u + 2 < U ? ws : wsn;         // (after the very last step: columns nobody reads)
-            nA[wn] = Vr[un].x;
-            nA[PVS + wn] = Vr[un].y;
-          }
+            if (c0i == 0) {
+              static_assert(U / 2 + 1 <= CH / 2, "the next pivot pair lies in the first chunk");
+              Vr[un] = __builtin_elementwise_fma(m1, pb[un], __builtin_elementwise_fma(m0, pa[un], Vr[un]));
+              const int wn = u + 2 < U ? ws : wsn;         // (after the very last step: columns nobody reads)
+              nA[wn] = Vr[un].x;
+              nA[PVS + wn] = Vr[un].y;
+            }
 #pragma unroll
-          for (int r = c0i / 2; r < c1i / 2; ++r)
-            if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
-          if (c1i < HN) BMPC_FENCE();
+            for (int r = c0i / 2; r < c1i / 2; ++r)
+              if (r != un) Vr[r] = __builtin_elementwise_fma(m1, pb[r - c0i / 2], __builtin_elementwise_fma(m0, pa[r - c0i / 2], Vr[r]));
+            if (c1i < HN) BMPC_FENCE();
+          }
+          if (hf == 0) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
         }
-        if (hf == 0) Vr[u >> 1] = is0 ? f2{-q00, -q01} : (is1 ? f2{-q01, -q11} : f2{t0, t1});
+        {                                        // rotate left by U across the pair
+          f2 tmp[U / 2];
+#pragma unroll
+          for (int u = 0; u < U / 2; ++u) tmp[u] = pair_swap(Vr[u]);
+#pragma unroll
+          for (int r = 0; r + U / 2 < HN / 2; ++r) Vr[r] = Vr[r + U / 2];
+#pragma unroll
+          for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
+        }
+        pos = posn;
+        ws = wsn;
+        BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
       }
-      {                                        // rotate left by U across the pair
-        f2 tmp[U / 2];
-#pragma unroll
-        for (int u = 0; u < U / 2; ++u) tmp[u] = pair_swap(Vr[u]);
-#pragma unroll
-        for (int r = 0; r + U / 2 < HN / 2; ++r) Vr[r] = Vr[r + U / 2];
-#pragma unroll
-        for (int u = 0; u < U / 2; ++u) Vr[HN / 2 - U / 2 + u] = tmp[u];
-      }
-      pos = posn;
-      ws = wsn;
-      BMPC_DRAIN_LDS();                         // nothing in flight across the back edge (see sync_workgroup)
-    }
     }
     piv_bad = !(qmax < 1.f / PIV_MIN) || !(qmin > 0.f);     // (an infinite reciprocal -- a zero determinant -- fails too)
     if constexpr (PROF) t_sweep += clock64() - t_mark;
