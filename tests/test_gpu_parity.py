@@ -905,7 +905,8 @@ def test_closed_loop_rollout_and_warm_start(gait):
     # measured: 0.60x in double support, 0.84x while the contact schedule advances every period -- of the
     # cold counts of round 4; the round-5 schedule took 20 % off a COLD solve (35.6 instead of 44.2 iterations here) and 4 % off a
     # warm one (25.4 instead of 26.5): 0.71x
-    assert out[True][1:].mean() < (0.78 if gait == "standing" else 0.95) * out[False][1:].mean()
+    # (iteration counts do not depend on the box: the bound is the measured ratio + 0.03; it was 0.78 in round 5)
+    assert out[True][1:].mean() < (0.745 if gait == "standing" else 0.94) * out[False][1:].mean()
 
 
 def test_reference_generators_dropin():
